@@ -1,0 +1,121 @@
+/* include/orip.h -- C ABI of liborip.so: the MI355X-native hot path of omnirevolve-image-processor
+ * (stages 02_color_extract -> 03_edge_detect -> 04_find_contours -> 05/07 glue -> 08_dedup_layer_basic ->
+ * 10_dedup_cross_basic -> 12_optimize_plot_order).
+ *
+ * The reference is pure Python and has NO FFI for this path: its stage API is "one script per stage,
+ * artefacts on disk" (pipeline.py:66-111).  Each entry point below therefore names the reference
+ * function (file:line under /root/reference/image_processor/) whose computation it replaces; the Python
+ * host (omnirevolve-image-processor_amd/orip/) binds them with ctypes and re-creates the stage scripts.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain C types; every function returns 0 on success, <0 on error (text via
+ * orip_last_error); one orip_ctx per device and host thread (not re-entrant); the caller owns every host
+ * buffer (C-contiguous, row-major); results stay RESIDENT on the device between calls ("slots") and are
+ * moved only by the explicit orip_get_ / orip_set_ calls, so the end-to-end path 02->12 touches the host
+ * only for the input image and the final ops.  Variable-length results use the two-call pattern
+ * (orip_polys_size then orip_get_polys).  There is no CPU fallback anywhere in the library.
+ */
+#ifndef ORIP_H
+#define ORIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orip_ctx orip_ctx;
+
+#define ORIP_MAX_LAYERS 16
+
+/* polyline-list slots (per layer), named after the artefact each one mirrors */
+enum {
+    ORIP_SLOT_CONTOURS = 0,     /* <layer>/contours.pkl         (04:226-228) */
+    ORIP_SLOT_SCALED = 1,       /* <layer>/contours_scaled.pkl  (05:124-127) */
+    ORIP_SLOT_SORTED = 2,       /* <layer>/contours_sorted.pkl  (07:91-92)   */
+    ORIP_SLOT_LINES_INTRA = 3,  /* <layer>/lines_intra.pkl      (08:548-549) */
+    ORIP_SLOT_LINES_CROSS = 4,  /* <layer>/lines_cross.pkl      (10:200-202) */
+    ORIP_SLOT_COUNT = 5
+};
+enum { ORIP_TAPS_INTRA = 0 /* taps_intra.pkl 08:550-551 */, ORIP_TAPS_CROSS = 1 /* taps_cross.pkl 10:203-204 */ };
+
+/* 08:484-509 derived parameters */
+typedef struct {
+    double tap_diam, tap_max_dim, min_keep, tap_max_per;
+    int32_t tap_max_v;
+    double sample_step, tail_len_px, col_rad, grid_stride, max_jump;
+    int32_t post_on, post_brush;
+    double post_step, post_eps;
+    int32_t post_minlen;
+    int32_t W, H;          /* canvas, 08:103-113 */
+    int32_t brush_forbid;
+} orip_params08;
+
+/* 10:217-229 derived parameters */
+typedef struct {
+    double tap_diam, min_keep, tap_max_per;
+    int32_t tap_max_v;
+    double max_jump, D_lines, D_taps, step_px;
+    int32_t W, H;
+} orip_params10;
+
+/* ---- context ---- */
+int orip_create(int device_id, orip_ctx** out);
+void orip_destroy(orip_ctx* ctx);
+const char* orip_last_error(orip_ctx* ctx);
+int orip_sync(orip_ctx* ctx);
+/* HIP-event timing of the named raster kernel since the last reset: total ms and launch count (bench.py roofline) */
+int orip_prof_reset(orip_ctx* ctx);
+int orip_prof_get(orip_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
+int orip_prof_enable(orip_ctx* ctx, int on);
+
+/* ---- stage 02: 02_color_extract.py ---- */
+/* upload the pixels of resized.png (BGR u8 [H,W,3]) -- replaces cv2.imread at 02:70-71 */
+int orip_set_image(orip_ctx* ctx, const uint8_t* bgr, int H, int W);
+/* cv2.cvtColor(BGR2LAB) (02:35) of the whole image or of the pixels idx[0..n) -> host u8 [n,3] (test hook) */
+int orip_lab_of(orip_ctx* ctx, const int64_t* idx, int64_t n, uint8_t* lab_out);
+/* _kmeans_lab fit part (02:39-49): Lab of the sampled pixels + cv2.kmeans(PP centres, attempts, (EPS|ITER)) */
+int orip_kmeans_fit(orip_ctx* ctx, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter,
+                    double eps, float* centers_out /* [K,3] in cv2.kmeans order */, double* compactness_out);
+/* assignment (02:53-55) + dark->light relabel (02:120-127) + per-cluster mask + 3x3 RECT open/close (02:144-154).
+ * Leaves labels u8 [H,W] (dark->light index) and K masks resident; layer l of the context = cluster l. */
+int orip_extract_layers(orip_ctx* ctx, const float* centers /* [K,3] */, int K, int open_iters, int close_iters,
+                        float* centers_sorted_out /* [K,3] */, int64_t* counts_out /* [K] pixels per cluster */);
+int orip_get_labels(orip_ctx* ctx, uint8_t* labels_out);
+int orip_get_mask(orip_ctx* ctx, int layer, uint8_t* mask_out);
+/* upload K masks [K,H,W] (stage 03 run stand-alone from mask.png files, 03:15-19) */
+int orip_set_masks(orip_ctx* ctx, const uint8_t* masks, int K, int H, int W);
+
+/* ---- stage 03: 03_edge_detect.py process_color (03:13-40), all layers in one call ---- */
+int orip_detect_edges(orip_ctx* ctx, int morph_k, int open_iters, int close_iters, int gauss_k, int low, int high);
+int orip_get_edges(orip_ctx* ctx, int layer, uint8_t* edges_out);
+int orip_set_edges(orip_ctx* ctx, const uint8_t* edges, int K, int H, int W);
+
+/* ---- stage 04: 04_find_contours.py vectorize_layer (04:214-230), all layers in one call ---- */
+int orip_find_contours(orip_ctx* ctx);
+int orip_get_skeleton(orip_ctx* ctx, int layer, uint8_t* skel_out); /* thinning_zhangsuen output (04:35-99) */
+
+/* ---- polyline-list / tap-list slots ---- */
+int orip_polys_size(orip_ctx* ctx, int slot, int layer, int64_t* n_polys, int64_t* n_points);
+int orip_get_polys(orip_ctx* ctx, int slot, int layer, int64_t* off /* [n+1] */, int32_t* pts /* [n_points,2] */);
+int orip_set_polys(orip_ctx* ctx, int slot, int layer, int64_t n_polys, const int64_t* off, const int32_t* pts);
+int orip_taps_size(orip_ctx* ctx, int which, int layer, int64_t* n);
+int orip_get_taps(orip_ctx* ctx, int which, int layer, int32_t* xy);
+int orip_set_taps(orip_ctx* ctx, int which, int layer, int64_t n, const int32_t* xy);
+int orip_set_layer_count(orip_ctx* ctx, int K);
+
+/* ---- stage 05: _scale_one (05:82-96): CONTOURS -> SCALED ---- */
+int orip_scale_vectors(orip_ctx* ctx, int layer, float sx, float sy, float dx, float dy);
+/* ---- stage 07: reorder_one_color (07:19-95): SCALED -> SORTED ---- */
+int orip_sort_contours(orip_ctx* ctx, int layer);
+/* ---- stage 08: process_layer (08:484-557): SORTED -> LINES_INTRA + TAPS_INTRA ---- */
+int orip_dedup_layer(orip_ctx* ctx, int layer, const orip_params08* prm);
+/* ---- stage 10: main (10:212-278): LINES/TAPS_INTRA -> LINES/TAPS_CROSS, layers visited in `order` ---- */
+int orip_dedup_cross(orip_ctx* ctx, const int32_t* order, int n_layers, const orip_params10* prm);
+/* ---- stage 12: _build_ops_for_layer (12:85-187): LINES/TAPS_CROSS -> ops ----
+ * ops are returned as 5 int32 each: (type 0 line / 1 tap, line index into LINES_CROSS, flip, x, y). */
+int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);
+int orip_get_ops(orip_ctx* ctx, int layer, int32_t* ops5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
