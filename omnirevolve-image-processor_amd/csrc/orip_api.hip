@@ -1,0 +1,116 @@
+// csrc/orip_api.hip -- context life-cycle, slot transfers and profiling hooks of liborip.so.
+#include "orip_ctx.h"
+
+extern "C" int orip_create(int device_id, orip_ctx** out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2;   // no GPU: fail loudly, there is no CPU path
+    if (device_id < 0 || device_id >= ndev) return -3;
+    if (hipSetDevice(device_id) != hipSuccess) return -4;
+    orip_ctx* c = new orip_ctx();
+    c->device = device_id;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
+    hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
+    if (c->flags.ensure(4096) != hipSuccess) { delete c; return -6; }
+    hipMemsetAsync(c->flags.p, 0, 4096, c->stream);
+    hipStreamSynchronize(c->stream);
+    *out = c;
+    return 0;
+}
+
+extern "C" void orip_destroy(orip_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->tmpE, &c->tmpF,
+                    &c->lab_tabs, &c->flags, &c->canvas};
+    for (DBuf* b : bufs) b->release();
+    for (auto& v : c->vtmp) v.release();
+    for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); }
+    for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
+    for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* orip_last_error(orip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int orip_sync(orip_ctx* c) {
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int orip_prof_enable(orip_ctx* c, int on) { c->prof_on = on != 0; return 0; }
+extern "C" int orip_prof_reset(orip_ctx* c) { c->prof.clear(); return 0; }
+extern "C" int orip_prof_get(orip_ctx* c, const char* kernel, double* total_ms, int64_t* launches) {
+    auto it = c->prof.find(kernel);
+    if (it == c->prof.end()) { *total_ms = 0; *launches = 0; return 0; }
+    *total_ms = it->second.ms; *launches = it->second.launches;
+    return 0;
+}
+
+extern "C" int orip_set_layer_count(orip_ctx* c, int K) {
+    if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range", K);
+    c->K = K;
+    return 0;
+}
+
+static int check_slot(orip_ctx* c, int slot, int layer) {
+    if (slot < 0 || slot >= ORIP_SLOT_COUNT || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad slot %d / layer %d", slot, layer);
+    return 0;
+}
+
+extern "C" int orip_polys_size(orip_ctx* c, int slot, int layer, int64_t* n, int64_t* total) {
+    ORIP_TRY(check_slot(c, slot, layer));
+    *n = c->polys[slot][layer].n; *total = c->polys[slot][layer].total;
+    return 0;
+}
+extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, int32_t* pts) {
+    ORIP_TRY(check_slot(c, slot, layer));
+    DPolys& P = c->polys[slot][layer];
+    if (P.n == 0) { off[0] = 0; return 0; }
+    HIPC(c, hipMemcpyAsync(off, P.off.p, (size_t)(P.n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const int64_t* off, const int32_t* pts) {
+    ORIP_TRY(check_slot(c, slot, layer));
+    if (n < 0) ORIP_FAIL(c, "negative count");
+    DPolys& P = c->polys[slot][layer];
+    int64_t total = n ? off[n] : 0;
+    HIPC(c, P.off.ensure((size_t)(n + 1) * 8 + 64));
+    HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
+    if (n) HIPC(c, hipMemcpyAsync(P.off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    else HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
+    if (total) HIPC(c, hipMemcpyAsync(P.pts.p, pts, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    P.n = n; P.total = total;
+    if (layer >= c->K) c->K = layer + 1;
+    return 0;
+}
+extern "C" int orip_taps_size(orip_ctx* c, int which, int layer, int64_t* n) {
+    if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");
+    *n = c->taps[which][layer].n;
+    return 0;
+}
+extern "C" int orip_get_taps(orip_ctx* c, int which, int layer, int32_t* xy) {
+    if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");
+    DTaps& T = c->taps[which][layer];
+    if (!T.n) return 0;
+    HIPC(c, hipMemcpyAsync(xy, T.xy.p, (size_t)T.n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int orip_set_taps(orip_ctx* c, int which, int layer, int64_t n, const int32_t* xy) {
+    if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS || n < 0) ORIP_FAIL(c, "bad taps slot");
+    DTaps& T = c->taps[which][layer];
+    HIPC(c, T.xy.ensure((size_t)std::max<int64_t>(n, 1) * 8 + 64));
+    if (n) { HIPC(c, hipMemcpyAsync(T.xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream)); HIPC(c, hipStreamSynchronize(c->stream)); }
+    T.n = n;
+    if (layer >= c->K) c->K = layer + 1;
+    return 0;
+}

@@ -1,0 +1,105 @@
+// csrc/orip_ctx.h -- device context of liborip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/orip.h"
+
+typedef uint8_t u8;
+
+#define ORIP_FAIL(ctx, ...)                                              \
+    do {                                                                 \
+        char _b[512];                                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
+        (ctx)->err = std::string(__func__) + ": " + _b;                  \
+        return -1;                                                       \
+    } while (0)
+
+#define HIPC(ctx, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) ORIP_FAIL(ctx, "%s -> %s", #call, hipGetErrorString(_e));        \
+    } while (0)
+
+#define ORIP_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+
+// Growable device buffer; contents are NOT preserved across growth unless keep=true.
+struct DBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, hipStream_t s = 0, bool keep = false) {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = bytes + bytes / 4 + 256;
+        void* np_ = nullptr;
+        hipError_t e = hipMalloc(&np_, ncap);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) { e = hipMemcpyAsync(np_, p, cap, hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return e; hipStreamSynchronize(s); }
+        if (p) hipFree(p);
+        p = np_; cap = ncap;
+        return hipSuccess;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Device polyline list: off int64[n+1], pts int32[2*total]
+struct DPolys {
+    DBuf off, pts;
+    int64_t n = 0, total = 0;
+};
+struct DTaps {
+    DBuf xy;  // int32[2*n]
+    int64_t n = 0;
+};
+
+struct ProfEntry { double ms = 0; int64_t launches = 0; };
+
+struct orip_ctx {
+    int device = 0;
+    hipStream_t stream = 0;
+    std::string err;
+    // image / raster state
+    int H = 0, W = 0, K = 0;
+    DBuf image;     // u8 [H,W,3] BGR
+    DBuf labels;    // u8 [H,W]
+    DBuf masks;     // u8 [K,H,W]
+    DBuf edges;     // u8 [K,H,W]
+    DBuf skel;      // u8 [K,H,W]
+    DBuf tmpA, tmpB, tmpC, tmpD, tmpE, tmpF;   // scratch
+    DBuf lab_tabs;  // u16 gamma[256] + u16 cbrt[3072] + i32 coeffs[9]
+    bool tabs_ready = false;
+    DBuf flags;     // small int scratch (device), 256 ints
+    void* h_pinned = nullptr;  // 4 KB pinned host scratch
+    // vector state
+    DPolys polys[ORIP_SLOT_COUNT][ORIP_MAX_LAYERS];
+    DTaps taps[2][ORIP_MAX_LAYERS];
+    DBuf ops[ORIP_MAX_LAYERS];
+    int64_t n_ops[ORIP_MAX_LAYERS] = {0};
+    DBuf canvas;    // stage 08 / 10 raster state
+    DBuf vtmp[12];  // vector-stage scratch
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// Time one kernel launch with HIP events on ctx->stream when profiling is enabled (bench.py roofline leg).
+struct ProfScope {
+    orip_ctx* c; const char* name;
+    ProfScope(orip_ctx* ctx, const char* n) : c(ctx), name(n) { if (c->prof_on) hipEventRecord(c->ev0, c->stream); }
+    ~ProfScope() {
+        if (!c->prof_on) return;
+        hipEventRecord(c->ev1, c->stream); hipEventSynchronize(c->ev1);
+        float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        auto& e = c->prof[name]; e.ms += ms; e.launches++;
+    }
+};
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// stage entry points implemented across the .hip files
+int orip_raster02_lab_tables(orip_ctx* c);

@@ -1,0 +1,556 @@
+// csrc/raster02.hip -- stage 02 (02_color_extract.py) on gfx950:
+//   lab_assign   : BGR u8 -> Lab u8 (cv2.cvtColor, 02:35) -> nearest centre (02:53-55) -> dark->light label (02:120-127)
+//   lab_gather   : Lab of the k-means subsample (02:39-44)
+//   kmeans_fit   : cv2.kmeans with KMEANS_PP_CENTERS (02:46-49), one persistent workgroup
+//   morph_pass   : erode / dilate with an arbitrary <=7x7 structuring element (02:151-154, 03:25-30)
+// All float arithmetic mirrors numpy / OpenCV evaluation order: compiled with -ffp-contract=off and written
+// with explicit __fmul_rn/__fadd_rn where the order matters.
+#include "orip_ctx.h"
+#include <cmath>
+#include <algorithm>
+
+// ------------------------------------------------------------------------------------------------
+// Lab tables, built on the host once per context.
+// ------------------------------------------------------------------------------------------------
+struct LabTabs { uint16_t gamma[256]; uint16_t cbrt[3072]; int32_t coef[9]; };
+
+int orip_raster02_lab_tables(orip_ctx* c) {
+    if (c->tabs_ready) return 0;
+    static LabTabs t;
+    for (int i = 0; i < 256; i++) {
+        double x = i / 255.0;
+        double g = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+        long v = std::lrint(255.0 * 8.0 * g);
+        t.gamma[i] = (uint16_t)std::min<long>(std::max<long>(v, 0), 65535);
+    }
+    for (int i = 0; i < 3072; i++) {
+        double x = i / (255.0 * 8.0);
+        double y = x < 0.008856 ? x * 7.787 + 0.13793103448275862 : std::cbrt(x);
+        long v = std::lrint(32768.0 * y);
+        t.cbrt[i] = (uint16_t)std::min<long>(std::max<long>(v, 0), 65535);
+    }
+    const double M[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    const double D65[3] = {0.950456, 1.0, 1.088754};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t.coef[i * 3 + j] = (int32_t)std::lrint(4096.0 * M[i * 3 + j] / D65[i]);
+    HIPC(c, c->lab_tabs.ensure(sizeof(LabTabs)));
+    HIPC(c, hipMemcpyAsync(c->lab_tabs.p, &t, sizeof(LabTabs), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->tabs_ready = true;
+    return 0;
+}
+
+struct LabLds { uint16_t gamma[256]; uint16_t cbrt[3072]; };
+
+__device__ __forceinline__ void lab_lds_load(LabLds* s, const LabTabs* t) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s->gamma[i] = t->gamma[i];
+    for (int i = threadIdx.x; i < 3072; i += blockDim.x) s->cbrt[i] = t->cbrt[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ void bgr2lab_px(const LabLds* s, const int32_t* C, int b8, int g8, int r8, int& L, int& a, int& b) {
+    int B = s->gamma[b8], G = s->gamma[g8], R = s->gamma[r8];
+    int fX = s->cbrt[descale(R * C[0] + G * C[1] + B * C[2], 12)];
+    int fY = s->cbrt[descale(R * C[3] + G * C[4] + B * C[5], 12)];
+    int fZ = s->cbrt[descale(R * C[6] + G * C[7] + B * C[8], 12)];
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    L = min(max(descale(Lscale * fY + Lshift, 15), 0), 255);
+    a = min(max(descale(500 * (fX - fY) + 128 * (1 << 15), 15), 0), 255);
+    b = min(max(descale(200 * (fY - fZ) + 128 * (1 << 15), 15), 0), 255);
+}
+
+struct Centers { float c[ORIP_MAX_LAYERS * 3]; uint8_t lut[ORIP_MAX_LAYERS]; int K; };
+
+__device__ __forceinline__ int nearest_center(const Centers& cs, int L, int a, int b) {
+    float p0 = (float)L, p1 = (float)a, p2 = (float)b;
+    float best = 0.f; int kb = 0;
+    for (int k = 0; k < cs.K; k++) {
+        float d0 = __fsub_rn(p0, cs.c[3 * k]), d1 = __fsub_rn(p1, cs.c[3 * k + 1]), d2 = __fsub_rn(p2, cs.c[3 * k + 2]);
+        float s = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+        if (k == 0 || s < best) { best = s; kb = k; }
+    }
+    return cs.lut[kb];
+}
+
+// 4 pixels per thread: 12 B in (3 dwords), 4 B out (1 dword).  Algorithmic traffic 3+1 B/px.
+__global__ __launch_bounds__(256) void k_lab_assign(const u8* __restrict__ bgr, u8* __restrict__ labels, int64_t npx,
+                                                     const LabTabs* __restrict__ tabs, Centers cs) {
+    __shared__ LabLds s;
+    __shared__ int32_t C[9];
+    if (threadIdx.x < 9) C[threadIdx.x] = tabs->coef[threadIdx.x];
+    lab_lds_load(&s, tabs);
+    int64_t ngrp = npx >> 2;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngrp; g += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(bgr + g * 12);
+        uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        u8 px[12] = {(u8)w0, (u8)(w0 >> 8), (u8)(w0 >> 16), (u8)(w0 >> 24), (u8)w1, (u8)(w1 >> 8), (u8)(w1 >> 16), (u8)(w1 >> 24),
+                     (u8)w2, (u8)(w2 >> 8), (u8)(w2 >> 16), (u8)(w2 >> 24)};
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int L, a, b; bgr2lab_px(&s, C, px[3 * j], px[3 * j + 1], px[3 * j + 2], L, a, b);
+            out |= (uint32_t)nearest_center(cs, L, a, b) << (8 * j);
+        }
+        reinterpret_cast<uint32_t*>(labels)[g] = out;
+    }
+    // tail (npx % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (npx & 3)) {
+        int64_t i = (npx & ~(int64_t)3) + threadIdx.x;
+        int L, a, b; bgr2lab_px(&s, C, bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2], L, a, b);
+        labels[i] = (u8)nearest_center(cs, L, a, b);
+    }
+}
+
+// Lab of selected pixels (idx == nullptr: pixel i itself)
+__global__ __launch_bounds__(256) void k_lab_gather(const u8* __restrict__ bgr, const int64_t* __restrict__ idx, int64_t n,
+                                                     u8* __restrict__ lab, const LabTabs* __restrict__ tabs) {
+    __shared__ LabLds s;
+    __shared__ int32_t C[9];
+    if (threadIdx.x < 9) C[threadIdx.x] = tabs->coef[threadIdx.x];
+    lab_lds_load(&s, tabs);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = idx ? idx[i] : i;
+        int L, a, b; bgr2lab_px(&s, C, bgr[3 * p], bgr[3 * p + 1], bgr[3 * p + 2], L, a, b);
+        lab[3 * i] = (u8)L; lab[3 * i + 1] = (u8)a; lab[3 * i + 2] = (u8)b;
+    }
+}
+
+__global__ void k_count_labels(const u8* __restrict__ labels, int64_t n, unsigned long long* counts) {
+    __shared__ unsigned int h[ORIP_MAX_LAYERS];
+    if (threadIdx.x < ORIP_MAX_LAYERS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[labels[i] & 15], 1u);
+    __syncthreads();
+    if (threadIdx.x < ORIP_MAX_LAYERS && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv2.kmeans as ONE persistent 1024-thread workgroup.  Samples are u8 Lab triples,
+// so kmeans++ works on exact integers; the sequential scans of the CPU algorithm are replaced by
+// order-independent exact equivalents (see DESIGN.md "kmeans_fit").
+// ------------------------------------------------------------------------------------------------
+#define KM_T 1024
+struct KmState { unsigned long long rng; };
+
+__device__ __forceinline__ unsigned km_next(unsigned long long& st) {
+    st = (unsigned long long)(unsigned)st * 4164903690ULL + (unsigned)(st >> 32);
+    return (unsigned)st;
+}
+__device__ __forceinline__ double km_double(unsigned long long& st) {
+    unsigned t = km_next(st);
+    unsigned long long v = ((unsigned long long)t << 32) | km_next(st);
+    return (double)v * 5.4210108624275221700372640043497e-20;
+}
+
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long r = 0;
+    for (int w = 0; w < KM_T / 64; w++) r += red[w];
+    return r;
+}
+// deterministic (fixed tree) double sum
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int w = 0; w < KM_T / 64; w++) r += red[w];
+    return r;
+}
+
+__device__ __forceinline__ int isq3(const u8* a, const u8* b) {
+    int d0 = (int)a[0] - b[0], d1 = (int)a[1] - b[1], d2 = (int)a[2] - b[2];
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+// hal::normL2Sqr_(sample, centre, 3) in float: s=0; s+=t*t per component
+__device__ __forceinline__ float fsq3(const u8* a, const float* c) {
+    float s = 0.f;
+    for (int j = 0; j < 3; j++) { float t = __fsub_rn((float)a[j], c[j]); s = __fadd_rn(s, __fmul_rn(t, t)); }
+    return s;
+}
+
+__global__ __launch_bounds__(KM_T) void k_kmeans_fit(const u8* __restrict__ data, int N, int K, int attempts, int maxCount,
+                                                      double epsilon, int32_t* __restrict__ dist0, int32_t* __restrict__ dist1,
+                                                      int32_t* __restrict__ dist2, int32_t* __restrict__ labels,
+                                                      float* __restrict__ centers_out, double* __restrict__ compact_out,
+                                                      int* __restrict__ status) {
+    __shared__ long long red[KM_T / 64];
+    __shared__ double redd[KM_T / 64];
+    __shared__ long long part[KM_T];
+    __shared__ float centers[ORIP_MAX_LAYERS * 3], old_centers[ORIP_MAX_LAYERS * 3];
+    __shared__ int csum[KM_T / 64][ORIP_MAX_LAYERS * 4];
+    __shared__ long long tot[ORIP_MAX_LAYERS * 4];
+    __shared__ int sh_ci, sh_flag;
+    __shared__ int pp_idx[ORIP_MAX_LAYERS];
+    __shared__ unsigned long long sh_key;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int chunk = (N + KM_T - 1) / KM_T;
+    const int lo = min(N, tid * chunk), hi = min(N, lo + chunk);
+    unsigned long long rng = 0xffffffffULL;   // identical in every thread
+    double best_compact = 1.79769313486231570815e+308;
+    int32_t *dist = dist0, *tdist = dist1, *tdist2 = dist2;
+
+    for (int a = 0; a < attempts; a++) {
+        double compactness = 0;
+        for (int iter = 0;;) {
+            double max_shift = iter == 0 ? 1.79769313486231570815e+308 : 0.0;
+            // swap(centers, old_centers)
+            __syncthreads();
+            if (tid < K * 3) { float t = centers[tid]; centers[tid] = old_centers[tid]; old_centers[tid] = t; }
+            __syncthreads();
+            if (iter == 0) {
+                // ---------------- generateCentersPP ----------------
+                int c0 = (int)(km_next(rng) % (unsigned)N);
+                if (tid == 0) pp_idx[0] = c0;
+                long long ls = 0;
+                for (int i = tid; i < N; i += KM_T) { int d = isq3(data + 3 * i, data + 3 * c0); dist[i] = d; ls += d; }
+                long long sum0 = block_sum_ll(ls, red);
+                for (int k = 1; k < K; k++) {
+                    long long bestSum = 0x7fffffffffffffffLL; int bestCenter = -1;
+                    for (int j = 0; j < 3; j++) {
+                        double p = km_double(rng) * (double)sum0;
+                        // ci = first index with inclusive prefix >= p, else N-1   (exact)
+                        long long cs = 0;
+                        for (int i = lo; i < hi; i++) cs += dist[i];
+                        part[tid] = cs;
+                        __syncthreads();
+                        if (tid == 0) {
+                            long long run = 0; int ci = N - 1; int t;
+                            for (t = 0; t < KM_T; t++) { if ((double)(run + part[t]) >= p) break; run += part[t]; }
+                            if (t < KM_T) {
+                                int l2 = min(N, t * chunk), h2 = min(N, l2 + chunk);
+                                for (int i = l2; i < h2; i++) { run += dist[i]; if ((double)run >= p) { ci = i; break; } }
+                            }
+                            // p <= 0 before any subtraction cannot happen (p>0 unless sum0==0); sum0==0: loop never breaks -> N-1
+                            if (ci > N - 1) ci = N - 1;
+                            sh_ci = ci;
+                        }
+                        __syncthreads();
+                        int ci = sh_ci;
+                        long long s = 0;
+                        for (int i = tid; i < N; i += KM_T) { int d = min(isq3(data + 3 * i, data + 3 * ci), dist[i]); tdist2[i] = d; s += d; }
+                        long long S = block_sum_ll(s, red);
+                        if (S < bestSum) { bestSum = S; bestCenter = ci; int32_t* t = tdist; tdist = tdist2; tdist2 = t; }
+                    }
+                    if (tid == 0) pp_idx[k] = bestCenter;
+                    sum0 = bestSum;
+                    { int32_t* t = dist; dist = tdist; tdist = t; }
+                    __syncthreads();
+                }
+                __syncthreads();
+                if (tid < K * 3) centers[tid] = (float)data[3 * pp_idx[tid / 3] + tid % 3];
+                __syncthreads();
+            } else {
+                // ---------------- recompute centres from labels ----------------
+                for (int i = tid; i < (KM_T / 64) * ORIP_MAX_LAYERS * 4; i += KM_T) (&csum[0][0])[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < N; i += KM_T) {
+                    int k = labels[i];
+                    atomicAdd(&csum[wave][k * 4 + 0], (int)data[3 * i]);
+                    atomicAdd(&csum[wave][k * 4 + 1], (int)data[3 * i + 1]);
+                    atomicAdd(&csum[wave][k * 4 + 2], (int)data[3 * i + 2]);
+                    atomicAdd(&csum[wave][k * 4 + 3], 1);
+                }
+                __syncthreads();
+                if (tid < K * 4) { long long t = 0; for (int w = 0; w < KM_T / 64; w++) t += csum[w][tid]; tot[tid] = t; }
+                __syncthreads();
+                // float accumulation in sample order is exact (== integer sum) while every partial sum < 2^24
+                if (tid == 0) {
+                    int bad = 0;
+                    for (int k = 0; k < K; k++) for (int j = 0; j < 3; j++) if (tot[k * 4 + j] >= (1LL << 24)) bad = 1;
+                    sh_flag = bad;
+                }
+                __syncthreads();
+                if (sh_flag) {
+                    // rare slow path: literal sequential float32 accumulation by one lane
+                    if (tid == 0) {
+                        float acc[ORIP_MAX_LAYERS * 3];
+                        for (int q = 0; q < K * 3; q++) acc[q] = 0.f;
+                        for (int i = 0; i < N; i++) { int k = labels[i]; for (int j = 0; j < 3; j++) acc[k * 3 + j] = __fadd_rn(acc[k * 3 + j], (float)data[3 * i + j]); }
+                        for (int q = 0; q < K * 3; q++) centers[q] = acc[q];
+                    }
+                } else if (tid < K * 3) centers[tid] = (float)tot[(tid / 3) * 4 + tid % 3];
+                __syncthreads();
+                // empty-cluster repair (sequential over k, as the reference)
+                for (int k = 0; k < K; k++) {
+                    if (tot[k * 4 + 3] != 0) continue;      // uniform branch (shared)
+                    int max_k = 0;
+                    for (int k1 = 1; k1 < K; k1++) if (tot[max_k * 4 + 3] < tot[k1 * 4 + 3]) max_k = k1;
+                    float nb[3]; float scale = 1.f / (float)tot[max_k * 4 + 3];
+                    for (int j = 0; j < 3; j++) nb[j] = __fmul_rn(centers[max_k * 3 + j], scale);
+                    // farthest point: max_dist <= dist  => last index among maxima
+                    unsigned long long key = 0;
+                    for (int i = tid; i < N; i += KM_T) {
+                        if (labels[i] != max_k) continue;
+                        float d = fsq3(data + 3 * i, nb);
+                        unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+                        if (kk >= key) key = kk;
+                    }
+                    if (tid == 0) sh_key = 0;
+                    __syncthreads();
+                    atomicMax(&sh_key, key);
+                    __syncthreads();
+                    int far_i = (int)(sh_key & 0xffffffffu);
+                    __syncthreads();
+                    if (tid == 0) {
+                        tot[max_k * 4 + 3]--; tot[k * 4 + 3]++; labels[far_i] = k;
+                        for (int j = 0; j < 3; j++) {
+                            float v = (float)data[3 * far_i + j];
+                            centers[max_k * 3 + j] = __fsub_rn(centers[max_k * 3 + j], v);
+                            centers[k * 3 + j] = __fadd_rn(centers[k * 3 + j], v);
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    for (int k = 0; k < K; k++) {
+                        float scale = 1.f / (float)tot[k * 4 + 3];
+                        for (int j = 0; j < 3; j++) centers[k * 3 + j] = __fmul_rn(centers[k * 3 + j], scale);
+                        if (iter > 0) {
+                            double d = 0;
+                            for (int j = 0; j < 3; j++) { double t = (double)__fsub_rn(centers[k * 3 + j], old_centers[k * 3 + j]); d = __dadd_rn(d, __dmul_rn(t, t)); }
+                            max_shift = fmax(max_shift, d);
+                        }
+                    }
+                    redd[0] = max_shift;
+                }
+                __syncthreads();
+                max_shift = redd[0];
+                __syncthreads();
+            }
+            ++iter;
+            bool last = (iter == max(maxCount, 2)) || (max_shift <= epsilon);
+            if (last) {
+                double s = 0;
+                for (int i = tid; i < N; i += KM_T) s += (double)fsq3(data + 3 * i, &centers[3 * labels[i]]);
+                compactness = block_sum_d(s, redd);
+                break;
+            } else {
+                for (int i = tid; i < N; i += KM_T) {
+                    float md = 0.f; int kb = 0;
+                    for (int k = 0; k < K; k++) { float d = fsq3(data + 3 * i, &centers[3 * k]); if (k == 0 || md > d) { md = d; kb = k; } }
+                    labels[i] = kb;
+                }
+                __syncthreads();
+            }
+        }
+        if (compactness < best_compact) {
+            best_compact = compactness;
+            if (tid < K * 3) centers_out[tid] = centers[tid];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { *compact_out = best_compact; *status = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Morphology: one erode/dilate pass with a k x k structuring element given as a bit mask (bit i*k+j).
+// Out-of-image neighbours never win (cv2 default border).  If labels_mode, the source is the label
+// map and the pixel value is (label == layer) ? 255 : 0  -- fuses `mask=(labels==k)*255` (02:150).
+// grid.z = layer.
+// ------------------------------------------------------------------------------------------------
+#define MT_X 64
+#define MT_Y 16
+__global__ __launch_bounds__(256) void k_morph_pass(const u8* __restrict__ src, u8* __restrict__ dst, int H, int W, int k,
+                                                     unsigned long long se, int dilate, int labels_mode) {
+    __shared__ u8 tile[MT_Y + 6][MT_X + 8];
+    const int r = k >> 1;
+    const int layer = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const u8* s = labels_mode ? src : src + plane * layer;
+    u8* d = dst + plane * layer;
+    const int x0 = blockIdx.x * MT_X, y0 = blockIdx.y * MT_Y;
+    const u8 neutral = dilate ? 0 : 255;
+    for (int i = threadIdx.x; i < (MT_Y + 2 * r) * (MT_X + 2 * r); i += blockDim.x) {
+        int ty = i / (MT_X + 2 * r), tx = i % (MT_X + 2 * r);
+        int y = y0 + ty - r, x = x0 + tx - r;
+        u8 v = neutral;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            u8 raw = s[(size_t)y * W + x];
+            v = labels_mode ? (raw == layer ? 255 : 0) : raw;
+        }
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MT_Y * MT_X; i += blockDim.x) {
+        int ty = i / MT_X, tx = i % MT_X;
+        int y = y0 + ty, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        int v = neutral;
+        for (int a = 0; a < k; a++)
+            for (int b = 0; b < k; b++)
+                if ((se >> (a * k + b)) & 1ULL) { int t = tile[ty + a][tx + b]; v = dilate ? max(v, t) : min(v, t); }
+        d[(size_t)y * W + x] = (u8)v;
+    }
+}
+
+static unsigned long long make_se_bits(int shape, int k) {
+    unsigned long long se = 0;
+    if (shape == 0) { for (int i = 0; i < k * k; i++) se |= 1ULL << i; return se; }
+    int r = k / 2, c = k / 2; double inv_r2 = r ? 1.0 / ((double)r * r) : 0;
+    for (int i = 0; i < k; i++) {
+        int dy = i - r, j1 = 0, j2 = 0;
+        if (std::abs(dy) <= r) { int dx = (int)std::lrint(c * std::sqrt((r * r - dy * dy) * inv_r2)); j1 = std::max(c - dx, 0); j2 = std::min(c + dx + 1, k); }
+        for (int j = j1; j < j2; j++) se |= 1ULL << (i * k + j);
+    }
+    return se;
+}
+
+// open (erode^n, dilate^n) then close (dilate^n, erode^n); src plane(s) -> dst plane(s); uses tmpA as ping-pong
+int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode) {
+    if (k < 1 || k > 7 || (k & 1) == 0) ORIP_FAIL(c, "structuring element size %d unsupported (odd, 1..7)", k);
+    int H = c->H, W = c->W; size_t plane = (size_t)H * W;
+    unsigned long long se = make_se_bits(shape, k);
+    std::vector<int> passes;   // 0 erode, 1 dilate
+    for (int i = 0; i < std::max(open_iters, 0); i++) passes.push_back(0);
+    for (int i = 0; i < std::max(open_iters, 0); i++) passes.push_back(1);
+    for (int i = 0; i < std::max(close_iters, 0); i++) passes.push_back(1);
+    for (int i = 0; i < std::max(close_iters, 0); i++) passes.push_back(0);
+    if (passes.empty()) passes.push_back(-1);   // identity copy via 1x1 "erode"
+    HIPC(c, c->tmpA.ensure(plane * K));
+    dim3 grid(cdiv(W, MT_X), cdiv(H, MT_Y), K), block(256);
+    const u8* cur = src; bool lm = labels_mode;
+    int np_ = (int)passes.size();
+    for (int i = 0; i < np_; i++) {
+        // choose outputs so that the last pass lands in dst
+        u8* out = ((np_ - 1 - i) % 2 == 0) ? dst : c->tmpA.as<u8>();
+        if (out == cur) ORIP_FAIL(c, "internal: in-place morph pass");
+        int kk = passes[i] < 0 ? 1 : k; unsigned long long ss = passes[i] < 0 ? 1ULL : se;
+        {
+            ProfScope ps(c, "k_morph_pass");
+            hipLaunchKernelGGL(k_morph_pass, grid, block, 0, c->stream, cur, out, H, W, kk, ss, passes[i] == 1 ? 1 : 0, lm ? 1 : 0);
+        }
+        cur = out; lm = false;
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int orip_set_image(orip_ctx* c, const uint8_t* bgr, int H, int W) {
+    if (!bgr || H <= 0 || W <= 0) ORIP_FAIL(c, "bad image %dx%d", W, H);
+    ORIP_TRY(orip_raster02_lab_tables(c));
+    c->H = H; c->W = W;
+    HIPC(c, c->image.ensure((size_t)H * W * 3 + 16));
+    HIPC(c, hipMemcpyAsync(c->image.p, bgr, (size_t)H * W * 3, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* lab_out) {
+    if (!c->image.p) ORIP_FAIL(c, "no image set");
+    if (!idx) n = (int64_t)c->H * c->W;
+    HIPC(c, c->tmpB.ensure((size_t)n * 3 + 16));
+    if (idx) { HIPC(c, c->tmpC.ensure((size_t)n * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, idx, (size_t)n * 8, hipMemcpyHostToDevice, c->stream)); }
+    hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(n, 256))), dim3(256), 0, c->stream, c->image.as<u8>(),
+                       idx ? c->tmpC.as<int64_t>() : nullptr, n, c->tmpB.as<u8>(), c->lab_tabs.as<LabTabs>());
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(lab_out, c->tmpB.p, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
+                               float* centers_out, double* compactness_out) {
+    if (!c->image.p) ORIP_FAIL(c, "no image set");
+    if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range 1..%d", K, ORIP_MAX_LAYERS);
+    int64_t N = sample_idx ? n_idx : (int64_t)c->H * c->W;
+    if (N < K || N > 0x7fffffff) ORIP_FAIL(c, "bad sample count %lld", (long long)N);
+    HIPC(c, c->tmpB.ensure((size_t)N * 3 + 16));
+    if (sample_idx) { HIPC(c, c->tmpC.ensure((size_t)N * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, sample_idx, (size_t)N * 8, hipMemcpyHostToDevice, c->stream)); }
+    {
+        ProfScope ps(c, "k_lab_gather");
+        hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(N, 256))), dim3(256), 0, c->stream, c->image.as<u8>(),
+                           sample_idx ? c->tmpC.as<int64_t>() : nullptr, N, c->tmpB.as<u8>(), c->lab_tabs.as<LabTabs>());
+    }
+    HIPC(c, c->tmpD.ensure((size_t)N * 4 * 4 + 256));
+    int32_t* base = c->tmpD.as<int32_t>();
+    HIPC(c, c->flags.ensure(1024));
+    attempts = std::max(attempts, 1);
+    double epsilon = std::max(eps, 0.0); epsilon *= epsilon;
+    int maxCount = std::min(std::max(max_iter, 2), 100);
+    if (K == 1) { attempts = 1; maxCount = 2; }
+    float* d_centers = (float*)((char*)c->flags.p + 256);
+    double* d_comp = (double*)((char*)c->flags.p + 512);
+    int* d_status = (int*)c->flags.p;
+    HIPC(c, hipMemsetAsync(c->flags.p, 0xff, 4, c->stream));
+    {
+        ProfScope ps(c, "k_kmeans_fit");
+        hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, c->stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
+                           base, base + N, base + 2 * N, base + 3 * N, d_centers, d_comp, d_status);
+    }
+    HIPC(c, hipGetLastError());
+    struct { float cen[ORIP_MAX_LAYERS * 3]; } hc; double comp; int st;
+    HIPC(c, hipMemcpyAsync(hc.cen, d_centers, sizeof(float) * K * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(&comp, d_comp, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (st != 0) ORIP_FAIL(c, "kmeans kernel did not complete (status %d)", st);
+    memcpy(centers_out, hc.cen, sizeof(float) * K * 3);
+    if (compactness_out) *compactness_out = comp;
+    return 0;
+}
+
+extern "C" int orip_extract_layers(orip_ctx* c, const float* centers, int K, int open_iters, int close_iters,
+                                   float* centers_sorted_out, int64_t* counts_out) {
+    if (!c->image.p) ORIP_FAIL(c, "no image set");
+    if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range", K);
+    int H = c->H, W = c->W; int64_t npx = (int64_t)H * W;
+    // order = argsort(L) (stable), lut[order] = arange (02:121-127)
+    std::vector<int> order(K);
+    for (int i = 0; i < K; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return centers[3 * a] < centers[3 * b]; });
+    Centers cs; cs.K = K;
+    for (int i = 0; i < K * 3; i++) cs.c[i] = centers[i];
+    for (int r = 0; r < K; r++) cs.lut[order[r]] = (uint8_t)r;
+    if (centers_sorted_out) for (int r = 0; r < K; r++) for (int j = 0; j < 3; j++) centers_sorted_out[3 * r + j] = centers[3 * order[r] + j];
+    c->K = K;
+    HIPC(c, c->labels.ensure((size_t)npx + 16));
+    HIPC(c, c->masks.ensure((size_t)npx * K));
+    {
+        ProfScope ps(c, "k_lab_assign");
+        hipLaunchKernelGGL(k_lab_assign, dim3(std::min<int64_t>(4096, std::max<int64_t>(1, cdiv(npx / 4, 256)))), dim3(256), 0, c->stream,
+                           c->image.as<u8>(), c->labels.as<u8>(), npx, c->lab_tabs.as<LabTabs>(), cs);
+    }
+    HIPC(c, hipGetLastError());
+    if (counts_out) {
+        HIPC(c, c->flags.ensure(1024));
+        unsigned long long* d_cnt = (unsigned long long*)((char*)c->flags.p + 768);
+        HIPC(c, hipMemsetAsync(d_cnt, 0, ORIP_MAX_LAYERS * 8, c->stream));
+        hipLaunchKernelGGL(k_count_labels, dim3(1024), dim3(256), 0, c->stream, c->labels.as<u8>(), npx, d_cnt);
+        unsigned long long h[ORIP_MAX_LAYERS];
+        HIPC(c, hipMemcpyAsync(h, d_cnt, ORIP_MAX_LAYERS * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < K; k++) counts_out[k] = (int64_t)h[k];
+    }
+    return orip_morph_open_close(c, c->labels.as<u8>(), c->masks.as<u8>(), K, 0, 3, open_iters, close_iters, true);
+}
+
+extern "C" int orip_get_labels(orip_ctx* c, uint8_t* out) {
+    if (!c->labels.p) ORIP_FAIL(c, "no labels resident");
+    HIPC(c, hipMemcpyAsync(out, c->labels.p, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int orip_get_mask(orip_ctx* c, int layer, uint8_t* out) {
+    if (!c->masks.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no mask for layer %d", layer);
+    size_t plane = (size_t)c->H * c->W;
+    HIPC(c, hipMemcpyAsync(out, c->masks.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, int W) {
+    if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
+    c->H = H; c->W = W; c->K = K;
+    HIPC(c, c->masks.ensure((size_t)H * W * K));
+    HIPC(c, hipMemcpyAsync(c->masks.p, masks, (size_t)H * W * K, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}

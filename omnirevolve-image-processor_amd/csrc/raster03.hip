@@ -1,0 +1,232 @@
+// csrc/raster03.hip -- stage 03 (03_edge_detect.py process_color, 03:13-40) on gfx950:
+//   open/close with MORPH_ELLIPSE(k,k)   -> orip_morph_open_close (raster02.hip)
+//   k_blur_sobel_nms : cv2.GaussianBlur((k,k),0) + Canny front half (Sobel 3x3, L1 magnitude, NMS) fused in LDS
+//   hysteresis       : Canny back half as 8-connected components of candidate pixels (union-find CCL),
+//                      a component is an edge iff it holds a strong pixel (order independent)
+// Also hosts the generic union-find CCL kernels reused by stage 04.
+#include "orip_ctx.h"
+#include <algorithm>
+
+int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode);
+
+// ------------------------------------------------------------------------------------------------
+// Gaussian (fixed tables) + Sobel + NMS.  Output map: 0 weak candidate, 1 not an edge,
+// 2 strong.  Tile 64x16 outputs; LDS: mask tile (halo r+2), blurred tile (halo 2), magnitude (halo 1).
+// ------------------------------------------------------------------------------------------------
+#define ET_X 64
+#define ET_Y 16
+#define EH_MAX 5   // r(<=3) + 2
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { p = p < 0 ? -p : 2 * (n - 1) - p; }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur_sobel_nms(const u8* __restrict__ masks, u8* __restrict__ map, int H, int W, int gk, int low, int high) {
+    __shared__ u8 M[ET_Y + 2 * EH_MAX][ET_X + 2 * EH_MAX];
+    __shared__ u8 B[ET_Y + 4][ET_X + 4];
+    __shared__ short MAG[ET_Y + 2][ET_X + 2];
+    const int r = gk >> 1, hm = r + 2;
+    const size_t plane = (size_t)H * W;
+    const u8* src = masks + plane * blockIdx.z;
+    u8* dst = map + plane * blockIdx.z;
+    const int x0 = blockIdx.x * ET_X, y0 = blockIdx.y * ET_Y;
+    const int mw = ET_X + 2 * hm, mh = ET_Y + 2 * hm;
+    for (int i = threadIdx.x; i < mw * mh; i += blockDim.x) {
+        int ty = i / mw, tx = i % mw;
+        int y = reflect101(y0 + ty - hm, H), x = reflect101(x0 + tx - hm, W);
+        M[ty][tx] = src[(size_t)y * W + x];
+    }
+    __syncthreads();
+    // blurred tile with halo 2; positions outside the image take the value at the clamped position (BORDER_REPLICATE for Sobel)
+    int w1, w2, w3, w0, shift;   // symmetric weights: w0 centre
+    if (gk == 3) { w0 = 2; w1 = 1; w2 = 0; w3 = 0; shift = 4; }
+    else if (gk == 5) { w0 = 6; w1 = 4; w2 = 1; w3 = 0; shift = 8; }
+    else { w0 = 72; w1 = 56; w2 = 28; w3 = 8; shift = 16; }
+    const int wt[4] = {w0, w1, w2, w3};
+    for (int i = threadIdx.x; i < (ET_Y + 4) * (ET_X + 4); i += blockDim.x) {
+        int ty = i / (ET_X + 4), tx = i % (ET_X + 4);
+        int y = y0 + ty - 2, x = x0 + tx - 2;
+        int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        // tile coordinates of the clamped centre (always inside the staged M because |y-yc|<=2 only at image borders)
+        int my = yc - (y0 - hm), mx = xc - (x0 - hm);
+        long long s = 0;
+        for (int a = -r; a <= r; a++) {
+            int rowsum = 0;
+            for (int b = -r; b <= r; b++) rowsum += wt[abs(b)] * (int)M[my + a][mx + b];
+            s += (long long)wt[abs(a)] * rowsum;
+        }
+        B[ty][tx] = (u8)((s + (1LL << (shift - 1))) >> shift);
+    }
+    __syncthreads();
+    // magnitude with halo 1 (0 outside the image)
+    for (int i = threadIdx.x; i < (ET_Y + 2) * (ET_X + 2); i += blockDim.x) {
+        int ty = i / (ET_X + 2), tx = i % (ET_X + 2);
+        int y = y0 + ty - 1, x = x0 + tx - 1;
+        int m = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            int by = ty + 1, bx = tx + 1;
+            int gx = ((int)B[by - 1][bx + 1] + 2 * (int)B[by][bx + 1] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by][bx - 1] + (int)B[by + 1][bx - 1]);
+            int gy = ((int)B[by + 1][bx - 1] + 2 * (int)B[by + 1][bx] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by - 1][bx] + (int)B[by - 1][bx + 1]);
+            m = abs(gx) + abs(gy);
+        }
+        MAG[ty][tx] = (short)m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ET_Y * ET_X; i += blockDim.x) {
+        int ty = i / ET_X, tx = i % ET_X;
+        int y = y0 + ty, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        int by = ty + 2, bx = tx + 2;
+        int xs = ((int)B[by - 1][bx + 1] + 2 * (int)B[by][bx + 1] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by][bx - 1] + (int)B[by + 1][bx - 1]);
+        int ys = ((int)B[by + 1][bx - 1] + 2 * (int)B[by + 1][bx] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by - 1][bx] + (int)B[by - 1][bx + 1]);
+        int my = ty + 1, mx = tx + 1;
+        int m = MAG[my][mx];
+        u8 res = 1;
+        if (m > low) {
+            int ax = abs(xs), ay = abs(ys) << 15;
+            int tg22x = ax * 13573;
+            bool keep;
+            if (ay < tg22x) keep = (m > MAG[my][mx - 1] && m >= MAG[my][mx + 1]);
+            else {
+                int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) keep = (m > MAG[my - 1][mx] && m >= MAG[my + 1][mx]);
+                else { int s = ((xs ^ ys) < 0) ? -1 : 1; keep = (m > MAG[my - 1][mx - s] && m > MAG[my + 1][mx + s]); }
+            }
+            if (keep) res = (m > high) ? 2 : 0;
+        }
+        dst[(size_t)y * W + x] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic 8-connected union-find CCL over "foreground" pixels.  Pixels are identified by their
+// BLOCK-RASTER id  ((y>>1)*Wb + (x>>1))*4 + (y&1)*2 + (x&1): the root (minimum id) of a component
+// then names the first 2x2 block, in block-raster order, that holds one of its pixels -- the label
+// order block-based CCL scanners produce.  par[] is indexed by id, per layer.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int px_id(int y, int x, int Wb) { return (((y >> 1) * Wb + (x >> 1)) << 2) | ((y & 1) << 1) | (x & 1); }
+
+__device__ __forceinline__ int uf_find(const int* L, int a) {
+    int p = L[a];
+    while (p != a) { a = p; p = L[a]; }
+    return a;
+}
+__device__ __forceinline__ void uf_unite(int* L, int a, int b) {
+    bool done;
+    do {
+        a = uf_find(L, a); b = uf_find(L, b);
+        if (a < b) { int old = atomicMin(&L[b], a); done = (old == b); b = old; }
+        else if (b < a) { int old = atomicMin(&L[a], b); done = (old == a); a = old; }
+        else done = true;
+    } while (!done);
+}
+
+// fgtest: 0 -> fg = (img != bg_value);  grid.z = layer
+__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ img, int* __restrict__ par, int H, int W, int bg_value) {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    const size_t plane = (size_t)H * W, pplane = (size_t)Wb * Hb * 4;
+    const u8* s = img + plane * blockIdx.z; int* L = par + pplane * blockIdx.z;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    int id = px_id(y, x, Wb);
+    L[id] = (s[(size_t)y * W + x] != bg_value) ? id : -1;
+}
+__global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ img, int* __restrict__ par, int H, int W, int bg_value) {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    const size_t plane = (size_t)H * W, pplane = (size_t)Wb * Hb * 4;
+    const u8* s = img + plane * blockIdx.z; int* L = par + pplane * blockIdx.z;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    if (s[(size_t)y * W + x] == bg_value) return;
+    int id = px_id(y, x, Wb);
+    if (x > 0 && s[(size_t)y * W + x - 1] != bg_value) uf_unite(L, id, px_id(y, x - 1, Wb));
+    if (y > 0) {
+        const u8* up = s + (size_t)(y - 1) * W;
+        if (x > 0 && up[x - 1] != bg_value) uf_unite(L, id, px_id(y - 1, x - 1, Wb));
+        if (up[x] != bg_value) uf_unite(L, id, px_id(y - 1, x, Wb));
+        if (x + 1 < W && up[x + 1] != bg_value) uf_unite(L, id, px_id(y - 1, x + 1, Wb));
+    }
+}
+// plane-aware flatten
+__global__ __launch_bounds__(256) void k_ccl_flatten2(int* __restrict__ par, int pplane) {
+    int* L = par + (size_t)pplane * blockIdx.z;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pplane) return;
+    if (L[i] < 0) return;
+    L[i] = uf_find(L, i);
+}
+
+int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value) {
+    int H = c->H, W = c->W;
+    int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1, pplane = Wb * Hb * 4;
+    dim3 grid(cdiv(W, 64), cdiv(H, 4), K), block(256);
+    if ((W & 1) || (H & 1)) HIPC(c, hipMemsetAsync(par, 0xff, (size_t)pplane * K * sizeof(int), c->stream));  // ids of absent pixels
+    { ProfScope ps(c, "k_ccl_init"); hipLaunchKernelGGL(k_ccl_init, grid, block, 0, c->stream, img, par, H, W, bg_value); }
+    { ProfScope ps(c, "k_ccl_merge"); hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, c->stream, img, par, H, W, bg_value); }
+    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_flatten2, dim3(cdiv(pplane, 256), 1, K), block, 0, c->stream, par, pplane); }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// hysteresis: mark roots that hold a strong pixel, then edge = candidate && marked(root)
+__global__ __launch_bounds__(256) void k_hyst_mark(const u8* __restrict__ map, const int* __restrict__ par, u8* __restrict__ strong_root, int H, int W) {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    const size_t plane = (size_t)H * W, pplane = (size_t)Wb * Hb * 4;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    if (map[plane * blockIdx.z + (size_t)y * W + x] != 2) return;
+    int root = par[pplane * blockIdx.z + px_id(y, x, Wb)];
+    strong_root[pplane * blockIdx.z + root] = 1;
+}
+__global__ __launch_bounds__(256) void k_hyst_out(const u8* __restrict__ map, const int* __restrict__ par, const u8* __restrict__ strong_root,
+                                                   u8* __restrict__ edges, int H, int W) {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    const size_t plane = (size_t)H * W, pplane = (size_t)Wb * Hb * 4;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = plane * blockIdx.z + (size_t)y * W + x;
+    u8 v = 0;
+    if (map[o] != 1) { int root = par[pplane * blockIdx.z + px_id(y, x, Wb)]; v = strong_root[pplane * blockIdx.z + root] ? 255 : 0; }
+    edges[o] = v;
+}
+
+extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int close_iters, int gauss_k, int low, int high) {
+    if (!c->masks.p || c->K < 1) ORIP_FAIL(c, "no masks resident (run orip_extract_layers or orip_set_masks)");
+    if (gauss_k != 3 && gauss_k != 5 && gauss_k != 7) ORIP_FAIL(c, "GaussianBlur kernel size %d unsupported (3, 5, 7)", gauss_k);
+    int H = c->H, W = c->W, K = c->K; size_t plane = (size_t)H * W;
+    if (low > high) std::swap(low, high);
+    HIPC(c, c->edges.ensure(plane * K));
+    HIPC(c, c->tmpB.ensure(plane * K));   // morphed masks
+    HIPC(c, c->tmpC.ensure(plane * K));   // NMS map
+    ORIP_TRY(orip_morph_open_close(c, c->masks.as<u8>(), c->tmpB.as<u8>(), K, 2, morph_k, open_iters, close_iters, false));
+    dim3 grid(cdiv(W, ET_X), cdiv(H, ET_Y), K), block(256);
+    { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, c->stream, c->tmpB.as<u8>(), c->tmpC.as<u8>(), H, W, gauss_k, low, high); }
+    HIPC(c, hipGetLastError());
+    int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; size_t pplane = (size_t)Wb * Hb * 4;
+    HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
+    HIPC(c, c->tmpE.ensure(pplane * K));
+    ORIP_TRY(orip_ccl(c, c->tmpC.as<u8>(), c->tmpD.as<int>(), K, 1));
+    HIPC(c, hipMemsetAsync(c->tmpE.p, 0, pplane * K, c->stream));
+    dim3 g2(cdiv(W, 64), cdiv(H, 4), K);
+    { ProfScope ps(c, "k_hyst_mark"); hipLaunchKernelGGL(k_hyst_mark, g2, block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), c->tmpE.as<u8>(), H, W); }
+    { ProfScope ps(c, "k_hyst_out"); hipLaunchKernelGGL(k_hyst_out, g2, block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), c->tmpE.as<u8>(), c->edges.as<u8>(), H, W); }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int orip_get_edges(orip_ctx* c, int layer, uint8_t* out) {
+    if (!c->edges.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no edges for layer %d", layer);
+    size_t plane = (size_t)c->H * c->W;
+    HIPC(c, hipMemcpyAsync(out, c->edges.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int orip_set_edges(orip_ctx* c, const uint8_t* edges, int K, int H, int W) {
+    if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
+    c->H = H; c->W = W; c->K = K;
+    HIPC(c, c->edges.ensure((size_t)H * W * K));
+    HIPC(c, hipMemcpyAsync(c->edges.p, edges, (size_t)H * W * K, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}

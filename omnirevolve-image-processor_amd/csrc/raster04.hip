@@ -1,0 +1,295 @@
+// csrc/raster04.hip -- stage 04 (04_find_contours.py vectorize_layer, 04:214-230) on gfx950:
+//   k_thin_sub        : one Zhang-Suen sub-iteration with the reference's rotated neighbour numbering (04:50-93)
+//   CCL               : union-find kernels of raster03.hip (component order = block-raster)
+//   k_skel_state      : per-pixel state byte (fg, endpoint deg==1, junction deg>=3)          (04:128-130)
+//   k_compact_*       : wavefront ballot / prefix-sum compaction of skeleton pixels in raster order (04:144,174)
+//   radix sort        : rocPRIM stable sort of (layer, component root) keys -> per-component pixel lists
+//   k_walk<WRITE>     : the centerline walker, one lane per component, exact serial semantics (04:137-205);
+//                       runs twice (count, then write); the guard-bounded "bounce" tails of phase-2 walks are
+//                       detected as cycles of the (prev,cur) state and written by k_expand_cycles in parallel.
+#include "orip_ctx.h"
+#include "walker.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value);
+
+// ------------------------------------------------------------------------------------------------
+// Thinning.  P2..P9 offsets (dy,dx) derived from the _shift() arguments at 04:53-55.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_thin_sub(const u8* __restrict__ src, u8* __restrict__ dst, int H, int W, int sub, int* __restrict__ changed) {
+    const size_t plane = (size_t)H * W;
+    const u8* s = src + plane * blockIdx.z; u8* d = dst + plane * blockIdx.z;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    u8 v = s[o];
+    if (v) {
+        auto g = [&](int dy, int dx) -> int { int yy = y + dy, xx = x + dx; return (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) ? 1 : 0; };
+        int P2 = g(1, 0), P3 = g(1, -1), P4 = g(0, -1), P5 = g(-1, -1), P6 = g(-1, 0), P7 = g(-1, 1), P8 = g(0, 1), P9 = g(1, 1);
+        int Bn = P2 + P3 + P4 + P5 + P6 + P7 + P8 + P9;
+        int A = (!P2 && P3) + (!P3 && P4) + (!P4 && P5) + (!P5 && P6) + (!P6 && P7) + (!P7 && P8) + (!P8 && P9) + (!P9 && P2);
+        bool cnd = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0) : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
+        if (A == 1 && Bn >= 2 && Bn <= 6 && cnd) { v = 0; *changed = 1; }
+    }
+    d[o] = v ? 255 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state byte: bit0 fg, bit1 visited, bit2 endpoint (deg==1), bit3 junction (deg>=3)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_skel_state(const u8* __restrict__ skel, u8* __restrict__ st, int H, int W) {
+    const size_t plane = (size_t)H * W;
+    const u8* s = skel + plane * blockIdx.z; u8* d = st + plane * blockIdx.z;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    u8 v = 0;
+    if (s[o]) {
+        int deg = 0;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                if (!dy && !dx) continue;
+                int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) deg++;
+            }
+        v = ST_FG | (deg == 1 ? ST_END : 0) | (deg >= 3 ? ST_JUN : 0);
+    }
+    d[o] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered compaction (raster order inside a layer, layers in order): ballot + popcount inside the wave,
+// LDS across the 4 waves of a block, block offsets from an exclusive scan of per-block counts.
+// One block = 1024 consecutive pixels of the flattened [K,H,W] array (4 per thread via one dword load).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_count(const u8* __restrict__ st, int64_t n, unsigned* __restrict__ counts) {
+    __shared__ unsigned wsum[4];
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned cnt = 0;
+    if (i + 3 < n) { uint32_t w = *reinterpret_cast<const uint32_t*>(st + i); cnt = ((w & 1) != 0) + (((w >> 8) & 1) != 0) + (((w >> 16) & 1) != 0) + (((w >> 24) & 1) != 0); }
+    else for (int j = 0; j < 4; j++) if (i + j < n && (st[i + j] & 1)) cnt++;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_compact_write(const u8* __restrict__ st, const int* __restrict__ par, int64_t n, int H, int W,
+                                                       const unsigned* __restrict__ block_off, unsigned* __restrict__ keys, unsigned* __restrict__ lin) {
+    __shared__ unsigned wsum[4];
+    const int64_t plane = (int64_t)H * W;
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const int64_t pplane = (int64_t)Wb * Hb * 4;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned f[4]; unsigned cnt = 0;
+    for (int j = 0; j < 4; j++) { f[j] = (i + j < n) ? (st[i + j] & 1u) : 0u; cnt += f[j]; }
+    // inclusive scan of cnt across the wave via shuffles, then across waves via LDS
+    unsigned inc = cnt;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned base = block_off[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += wsum[w];
+    unsigned pos = base + inc - cnt;
+    for (int j = 0; j < 4; j++) {
+        if (!f[j]) continue;
+        int64_t g = i + j; int layer = (int)(g / plane); int64_t p = g - (int64_t)layer * plane;
+        int y = (int)(p / W), x = (int)(p % W);
+        int id = (((y >> 1) * Wb + (x >> 1)) << 2) | ((y & 1) << 1) | (x & 1);
+        unsigned root = (unsigned)par[pplane * layer + id];
+        keys[pos] = ((unsigned)layer << 26) | root;
+        lin[pos] = (unsigned)p;
+        pos++;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_heads(const unsigned* __restrict__ keys, int64_t m, unsigned* __restrict__ head) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// comp_start[c] = first element of component c; comp_start[nc] = m
+__global__ __launch_bounds__(256) void k_comp_starts(const unsigned* __restrict__ head, const unsigned* __restrict__ head_scan, int64_t m,
+                                                     unsigned* __restrict__ comp_start, unsigned nc) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) comp_start[nc] = (unsigned)m;
+    if (i >= m) return;
+    if (head[i]) comp_start[head_scan[i]] = (unsigned)i;
+}
+__global__ __launch_bounds__(256) void k_gather_head_layers(const unsigned* __restrict__ keys, const unsigned* __restrict__ cs, unsigned nc, unsigned* __restrict__ out) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nc) out[i] = keys[cs[i]] >> 26;
+}
+__global__ __launch_bounds__(256) void k_clear_visited(u8* __restrict__ st, const unsigned* __restrict__ keys, const unsigned* __restrict__ lin, int64_t m, int64_t plane) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    st[plane * (keys[i] >> 26) + lin[i]] &= (u8)~ST_VIS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Walker.  NEIGH8 order (dx,dy) from 04:12.
+// ------------------------------------------------------------------------------------------------
+#include "walker.h"
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_walk(WalkArgs A) {
+    unsigned c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= A.nc) return;
+    walk_component<WRITE>(A, c);
+}
+
+// one block per descriptor (grid-stride): dst[pos + j] = dst[pos - lam + (j % lam)]
+__global__ __launch_bounds__(256) void k_expand_cycles(const unsigned long long* __restrict__ desc, const unsigned* __restrict__ n_desc, WalkArgs A) {
+    unsigned nd = min(*n_desc, A.desc_cap);
+    for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
+        const unsigned long long* e = desc + 4ull * d;
+        int layer = (int)e[0]; unsigned long long pos = e[1], lam = e[2], cnt = e[3];
+        int2* out = reinterpret_cast<int2*>(A.pts[layer]);
+        for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) out[pos + j] = out[pos - lam + (j % lam)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rocPRIM helpers
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static int excl_scan(orip_ctx* c, const T* in, T* out, size_t n, DBuf& tmp) {
+    size_t bytes = 0;
+    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    HIPC(c, tmp.ensure(bytes + 16));
+    HIPC(c, rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    return 0;
+}
+
+extern "C" int orip_find_contours(orip_ctx* c) {
+    if (!c->edges.p || c->K < 1) ORIP_FAIL(c, "no edges resident (run orip_detect_edges or orip_set_edges)");
+    const int H = c->H, W = c->W, K = c->K;
+    if (H > 8192 || W > 8192) ORIP_FAIL(c, "image %dx%d exceeds the 8192x8192 limit of the component key packing", W, H);
+    const size_t plane = (size_t)H * W; const int64_t n = (int64_t)plane * K;
+    // ---- thinning_zhangsuen (04:35-99): <=120 iterations of two sub-iterations, until nothing is deleted
+    HIPC(c, c->skel.ensure(plane * K + 16));
+    HIPC(c, c->tmpB.ensure(plane * K + 16));
+    HIPC(c, c->flags.ensure(1024));
+    int* d_changed = c->flags.as<int>() + 8;
+    dim3 g2(cdiv(W, 64), cdiv(H, 4), K), block(256);
+    {
+        // iteration 1 reads the edges; ping-pong skel <-> tmpB so that the result always lands in skel
+        const u8* cur = c->edges.as<u8>();
+        for (int it = 0; it < 120; it++) {
+            HIPC(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, c->stream, cur, c->tmpB.as<u8>(), H, W, 0, d_changed); }
+            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, c->stream, c->tmpB.as<u8>(), c->skel.as<u8>(), H, W, 1, d_changed); }
+            cur = c->skel.as<u8>();
+            int h_changed = 0;
+            HIPC(c, hipMemcpyAsync(&h_changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (!h_changed) break;
+        }
+    }
+    // ---- components, state bytes
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
+    HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
+    ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
+    HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
+    { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, c->stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
+    // ---- ordered compaction
+    const int nblk = cdiv(n, 1024);
+    HIPC(c, c->tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
+    unsigned* d_cnt = c->tmpE.as<unsigned>(); unsigned* d_boff = d_cnt + nblk + 1;
+    HIPC(c, hipMemsetAsync(d_cnt + nblk, 0, sizeof(unsigned), c->stream));
+    { ProfScope ps(c, "k_compact_count"); hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, c->stream, c->tmpC.as<u8>(), n, d_cnt); }
+    ORIP_TRY(excl_scan<unsigned>(c, d_cnt, d_boff, (size_t)nblk + 1, c->tmpF));
+    // per-layer fg totals = differences of the scan at layer boundaries (blocks do not align with layers -> count on host from scan + partial)
+    unsigned M = 0;
+    HIPC(c, hipMemcpyAsync(&M, d_boff + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int l = 0; l < K; l++) {
+        DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
+        P.n = 0; P.total = 0;
+        HIPC(c, P.off.ensure(8)); HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
+    }
+    if (M == 0) return 0;
+    // keys / lin (double buffers for the sort)
+    HIPC(c, c->vtmp[0].ensure((size_t)M * 4 * 4 + 64));
+    unsigned* keys_in = c->vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
+    { ProfScope ps(c, "k_compact_write"); hipLaunchKernelGGL(k_compact_write, dim3(nblk), block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), n, H, W, d_boff, keys_in, lin_in); }
+    {
+        size_t bytes = 0;
+        HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, c->stream));
+        HIPC(c, c->tmpF.ensure(bytes + 16));
+        ProfScope ps(c, "radix_sort_pairs");
+        HIPC(c, rocprim::radix_sort_pairs(c->tmpF.p, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, c->stream));
+    }
+    // ---- component segmentation
+    HIPC(c, c->vtmp[1].ensure((size_t)M * 2 * 4 + 64));
+    unsigned* head = c->vtmp[1].as<unsigned>(); unsigned* head_scan = head + M;
+    hipLaunchKernelGGL(k_heads, dim3(cdiv(M, 256)), block, 0, c->stream, keys, (int64_t)M, head);
+    ORIP_TRY(excl_scan<unsigned>(c, head, head_scan, (size_t)M, c->tmpF));
+    unsigned last2[2];
+    HIPC(c, hipMemcpyAsync(&last2[0], head_scan + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(&last2[1], head + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const unsigned NC = last2[0] + last2[1];
+    HIPC(c, c->vtmp[2].ensure((size_t)(NC + 2) * 4 + 64));
+    unsigned* comp_start = c->vtmp[2].as<unsigned>();
+    hipLaunchKernelGGL(k_comp_starts, dim3(cdiv(M, 256)), block, 0, c->stream, head, head_scan, (int64_t)M, comp_start, NC);
+    // per-layer fg totals and first-component index: binary search on the sorted keys (host side, small readback)
+    std::vector<unsigned> h_cs(NC + 1), h_keyfirst(NC);
+    HIPC(c, hipMemcpyAsync(h_cs.data(), comp_start, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    // layer of each component (key of its first element)
+    HIPC(c, c->vtmp[3].ensure((size_t)NC * 4 + 64));
+    WalkArgs A; memset(&A, 0, sizeof(A));
+    A.H = H; A.W = W; A.plane = (int64_t)plane; A.st = c->tmpC.as<u8>(); A.keys = keys; A.lin = lin; A.comp_start = comp_start; A.nc = NC;
+    hipLaunchKernelGGL(k_gather_head_layers, dim3(cdiv(NC, 256)), block, 0, c->stream, keys, comp_start, NC, c->vtmp[3].as<unsigned>());
+    HIPC(c, hipMemcpyAsync(h_keyfirst.data(), c->vtmp[3].p, (size_t)NC * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned> layer_first(K + 1, NC);
+    for (unsigned i = NC; i-- > 0;) layer_first[h_keyfirst[i]] = i;
+    for (int l = K - 1; l >= 0; l--) if (layer_first[l] == NC && l + 1 <= K) layer_first[l] = layer_first[l + 1];
+    layer_first[K] = NC;
+    for (int l = 0; l < K; l++) A.total_fg[l] = (long long)h_cs[layer_first[l + 1]] - (long long)h_cs[layer_first[l]];
+    // ---- count pass
+    HIPC(c, c->vtmp[4].ensure((size_t)(NC + 1) * (8 + 8 + 4 + 4) + 256));
+    unsigned long long* comp_pts = c->vtmp[4].as<unsigned long long>(); unsigned long long* pts_base = comp_pts + (NC + 1);
+    unsigned* comp_paths = (unsigned*)(pts_base + (NC + 1)); unsigned* path_base = comp_paths + (NC + 1);
+    HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, c->stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, c->stream));
+    A.comp_pts = comp_pts; A.comp_paths = comp_paths; A.pts_base = pts_base; A.path_base = path_base;
+    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, A); }
+    HIPC(c, hipGetLastError());
+    ORIP_TRY(excl_scan<unsigned long long>(c, comp_pts, pts_base, (size_t)NC + 1, c->tmpF));
+    ORIP_TRY(excl_scan<unsigned>(c, comp_paths, path_base, (size_t)NC + 1, c->tmpF));
+    std::vector<unsigned long long> h_pb(NC + 1); std::vector<unsigned> h_qb(NC + 1);
+    HIPC(c, hipMemcpyAsync(h_pb.data(), pts_base, (size_t)(NC + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(h_qb.data(), path_base, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int l = 0; l < K; l++) {
+        DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
+        A.layer_pts_base[l] = h_pb[layer_first[l]]; A.layer_path_base[l] = h_qb[layer_first[l]];
+        P.total = (int64_t)(h_pb[layer_first[l + 1]] - h_pb[layer_first[l]]);
+        P.n = (int64_t)(h_qb[layer_first[l + 1]] - h_qb[layer_first[l]]);
+        HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
+        HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
+        HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
+        A.pts[l] = P.pts.as<int32_t>(); A.off[l] = P.off.as<int64_t>();
+    }
+    // ---- write pass
+    hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, c->stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);
+    // one descriptor per bounce walk; bounded by the number of skeleton pixels
+    HIPC(c, c->vtmp[5].ensure((size_t)M * 32 + 64));
+    A.desc = c->vtmp[5].as<unsigned long long>(); A.desc_cap = M;
+    A.n_desc = (unsigned*)(c->flags.as<int>() + 16);
+    HIPC(c, hipMemsetAsync(A.n_desc, 0, 4, c->stream));
+    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, A); }
+    { ProfScope ps(c, "k_expand_cycles"); hipLaunchKernelGGL(k_expand_cycles, dim3(4096), block, 0, c->stream, A.desc, A.n_desc, A); }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int orip_get_skeleton(orip_ctx* c, int layer, uint8_t* out) {
+    if (!c->skel.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no skeleton for layer %d", layer);
+    size_t plane = (size_t)c->H * c->W;
+    HIPC(c, hipMemcpyAsync(out, c->skel.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}

@@ -1,0 +1,198 @@
+"""Device: one orip_ctx (one GPU, one HIP stream) with numpy-array marshalling around the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _l
+
+
+class OripError(RuntimeError):
+    pass
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Device:
+    def __init__(self, device_id: int = 0):
+        self.L = _l.load()
+        h = C.c_void_p()
+        rc = self.L.orip_create(int(device_id), C.byref(h))
+        if rc != 0 or not h:
+            raise OripError(f"orip_create(device={device_id}) failed with {rc}: no usable MI355X (there is no CPU fallback)")
+        self.h = h
+        self.H = self.W = self.K = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise OripError((self.L.orip_last_error(self.h) or b"?").decode())
+
+    def sync(self):
+        self._ck(self.L.orip_sync(self.h))
+
+    # ---- profiling hooks (bench.py roofline leg)
+    def prof_enable(self, on: bool): self._ck(self.L.orip_prof_enable(self.h, int(on)))
+    def prof_reset(self): self._ck(self.L.orip_prof_reset(self.h))
+
+    def prof_get(self, kernel: str) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._ck(self.L.orip_prof_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- stage 02
+    def set_image(self, bgr: np.ndarray):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        if bgr.ndim == 2:  # _ensure_bgr (02:25-30)
+            bgr = np.ascontiguousarray(np.repeat(bgr[:, :, None], 3, axis=2))
+        assert bgr.ndim == 3 and bgr.shape[2] == 3
+        self.H, self.W = bgr.shape[:2]
+        self._img_ref = bgr  # keep alive until the async copy is consumed
+        self._ck(self.L.orip_set_image(self.h, _p(bgr), self.H, self.W))
+        self.sync()
+
+    def lab_of(self, idx: np.ndarray | None = None) -> np.ndarray:
+        if idx is None:
+            out = np.empty((self.H, self.W, 3), np.uint8)
+            self._ck(self.L.orip_lab_of(self.h, None, 0, _p(out)))
+            return out
+        idx = np.ascontiguousarray(idx, np.int64)
+        out = np.empty((len(idx), 3), np.uint8)
+        self._ck(self.L.orip_lab_of(self.h, _p(idx), len(idx), _p(out)))
+        return out
+
+    def kmeans_fit(self, sample_idx: np.ndarray | None, K: int, attempts=3, max_iter=40, eps=0.5) -> Tuple[np.ndarray, float]:
+        centers = np.zeros((K, 3), np.float32)
+        comp = C.c_double(0)
+        if sample_idx is None:
+            self._ck(self.L.orip_kmeans_fit(self.h, None, 0, K, attempts, max_iter, eps, _p(centers), C.byref(comp)))
+        else:
+            idx = np.ascontiguousarray(sample_idx, np.int64)
+            self._ck(self.L.orip_kmeans_fit(self.h, _p(idx), len(idx), K, attempts, max_iter, eps, _p(centers), C.byref(comp)))
+        return centers, comp.value
+
+    def extract_layers(self, centers: np.ndarray, open_iters=1, close_iters=1, want_counts=True):
+        c = np.ascontiguousarray(centers, np.float32)
+        K = len(c)
+        cs = np.zeros((K, 3), np.float32)
+        counts = np.zeros(K, np.int64)
+        self._ck(self.L.orip_extract_layers(self.h, _p(c), K, open_iters, close_iters, _p(cs), _p(counts) if want_counts else None))
+        self.K = K
+        return cs, counts
+
+    def get_labels(self) -> np.ndarray:
+        out = np.empty((self.H, self.W), np.uint8)
+        self._ck(self.L.orip_get_labels(self.h, _p(out)))
+        return out
+
+    def get_mask(self, layer: int) -> np.ndarray:
+        out = np.empty((self.H, self.W), np.uint8)
+        self._ck(self.L.orip_get_mask(self.h, layer, _p(out)))
+        return out
+
+    def set_masks(self, masks: np.ndarray):
+        m = np.ascontiguousarray(masks, np.uint8)
+        self.K, self.H, self.W = m.shape
+        self._ck(self.L.orip_set_masks(self.h, _p(m), self.K, self.H, self.W))
+        self.sync()
+
+    # ---- stage 03
+    def detect_edges(self, morph_k=3, open_iters=1, close_iters=1, gauss_k=3, low=50, high=150):
+        self._ck(self.L.orip_detect_edges(self.h, morph_k, open_iters, close_iters, gauss_k, int(low), int(high)))
+
+    def get_edges(self, layer: int) -> np.ndarray:
+        out = np.empty((self.H, self.W), np.uint8)
+        self._ck(self.L.orip_get_edges(self.h, layer, _p(out)))
+        return out
+
+    def set_edges(self, edges: np.ndarray):
+        e = np.ascontiguousarray(edges, np.uint8)
+        self.K, self.H, self.W = e.shape
+        self._ck(self.L.orip_set_edges(self.h, _p(e), self.K, self.H, self.W))
+        self.sync()
+
+    # ---- stage 04
+    def find_contours(self):
+        self._ck(self.L.orip_find_contours(self.h))
+
+    def get_skeleton(self, layer: int) -> np.ndarray:
+        out = np.empty((self.H, self.W), np.uint8)
+        self._ck(self.L.orip_get_skeleton(self.h, layer, _p(out)))
+        return out
+
+    # ---- slots
+    def polys_size(self, slot: int, layer: int) -> Tuple[int, int]:
+        n, t = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.orip_polys_size(self.h, slot, layer, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def get_polys_flat(self, slot: int, layer: int) -> Tuple[np.ndarray, np.ndarray]:
+        n, t = self.polys_size(slot, layer)
+        off = np.zeros(n + 1, np.int64)
+        pts = np.zeros((max(t, 1), 2), np.int32)
+        self._ck(self.L.orip_get_polys(self.h, slot, layer, _p(off), _p(pts)))
+        return off, pts[:t]
+
+    def get_polys(self, slot: int, layer: int) -> List[np.ndarray]:
+        off, pts = self.get_polys_flat(slot, layer)
+        return [pts[off[i]:off[i + 1]].reshape(-1, 1, 2) for i in range(len(off) - 1)]
+
+    def set_polys(self, slot: int, layer: int, polys: Sequence[np.ndarray]):
+        n = len(polys)
+        flat = [np.asarray(p).reshape(-1, 2).astype(np.int32) for p in polys]
+        off = np.zeros(n + 1, np.int64)
+        for i, p in enumerate(flat):
+            off[i + 1] = off[i] + len(p)
+        pts = np.ascontiguousarray(np.concatenate(flat, 0) if n else np.zeros((1, 2), np.int32), np.int32)
+        self._ck(self.L.orip_set_polys(self.h, slot, layer, n, _p(off), _p(pts)))
+
+    def get_taps(self, which: int, layer: int) -> List[Tuple[int, int]]:
+        n = C.c_int64(0)
+        self._ck(self.L.orip_taps_size(self.h, which, layer, C.byref(n)))
+        a = np.zeros((max(n.value, 1), 2), np.int32)
+        self._ck(self.L.orip_get_taps(self.h, which, layer, _p(a)))
+        return [(int(x), int(y)) for x, y in a[:n.value]]
+
+    def set_taps(self, which: int, layer: int, taps: Sequence[Tuple[int, int]]):
+        a = np.ascontiguousarray(np.asarray(list(taps), np.int32).reshape(-1, 2))
+        self._ck(self.L.orip_set_taps(self.h, which, layer, len(a), _p(a) if len(a) else None))
+
+    def set_layer_count(self, K: int):
+        self._ck(self.L.orip_set_layer_count(self.h, K))
+        self.K = K
+
+    # ---- stages 05 .. 12
+    def scale_vectors(self, layer: int, sx, sy, dx, dy):
+        self._ck(self.L.orip_scale_vectors(self.h, layer, np.float32(sx), np.float32(sy), np.float32(dx), np.float32(dy)))
+
+    def sort_contours(self, layer: int):
+        self._ck(self.L.orip_sort_contours(self.h, layer))
+
+    def dedup_layer(self, layer: int, prm: _l.Params08):
+        self._ck(self.L.orip_dedup_layer(self.h, layer, C.byref(prm)))
+
+    def dedup_cross(self, order: Sequence[int], prm: _l.Params10):
+        o = np.ascontiguousarray(np.asarray(list(order), np.int32))
+        self._ck(self.L.orip_dedup_cross(self.h, _p(o), len(o), C.byref(prm)))
+
+    def plot_order(self, layer: int, R_insert: float) -> np.ndarray:
+        n = C.c_int64(0)
+        self._ck(self.L.orip_plot_order(self.h, layer, float(R_insert), C.byref(n)))
+        ops = np.zeros((max(n.value, 1), 5), np.int32)
+        if n.value:
+            self._ck(self.L.orip_get_ops(self.h, layer, _p(ops)))
+        return ops[:n.value]

@@ -1,0 +1,66 @@
+// tests/host/walk_harness.cpp -- TEST INFRASTRUCTURE.  Compiles the product's serial walker (csrc/walker.h)
+// with g++ and drives it on the CPU, so the walk logic (phases, guards, cycle fast-forward) can be checked
+// against the golden traces and the oracle without a GPU.  The surrounding prep (components, state bytes) is a
+// plain host re-implementation that exists only in this harness.
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdint>
+#include "../../omnirevolve-image-processor_amd/csrc/walker.h"
+
+extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out, int64_t off_cap, int32_t* pts_out, int64_t pts_cap,
+                            int64_t* n_paths, int64_t* n_pts) {
+    size_t N = (size_t)H * W;
+    std::vector<uint8_t> st(N, 0);
+    std::vector<int> root(N, -1);
+    int Wb = (W + 1) / 2;
+    auto pid = [&](int y, int x) { return (((y >> 1) * Wb + (x >> 1)) << 2) | ((y & 1) << 1) | (x & 1); };
+    // flood fill components, root = min block-raster id
+    std::vector<size_t> stack, members;
+    for (size_t s = 0; s < N; s++) {
+        if (!skel[s] || root[s] >= 0) continue;
+        members.clear(); stack.push_back(s); root[s] = 0; int best = 1 << 30;
+        while (!stack.empty()) {
+            size_t i = stack.back(); stack.pop_back(); members.push_back(i);
+            int y = (int)(i / W), x = (int)(i % W); best = std::min(best, pid(y, x));
+            for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+                int yy = y + dy, xx = x + dx; if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                size_t j = (size_t)yy * W + xx; if (skel[j] && root[j] < 0) { root[j] = 0; stack.push_back(j); }
+            }
+        }
+        for (size_t i : members) root[i] = best;
+    }
+    std::vector<std::pair<unsigned, unsigned>> kl;   // (key, lin) raster order then stable sort
+    for (size_t i = 0; i < N; i++) if (skel[i]) {
+        int y = (int)(i / W), x = (int)(i % W), deg = 0;
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) { if (!dy && !dx) continue; int yy = y + dy, xx = x + dx; if (yy >= 0 && yy < H && xx >= 0 && xx < W && skel[(size_t)yy * W + xx]) deg++; }
+        st[i] = ST_FG | (deg == 1 ? ST_END : 0) | (deg >= 3 ? ST_JUN : 0);
+        kl.push_back({(unsigned)root[i], (unsigned)i});
+    }
+    *n_paths = 0; *n_pts = 0; off_out[0] = 0;
+    if (kl.empty()) return 0;
+    std::stable_sort(kl.begin(), kl.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    unsigned M = (unsigned)kl.size();
+    std::vector<unsigned> keys(M), lin(M), cs;
+    for (unsigned i = 0; i < M; i++) { keys[i] = kl[i].first; lin[i] = kl[i].second; if (i == 0 || keys[i] != keys[i - 1]) cs.push_back(i); }
+    unsigned NC = (unsigned)cs.size(); cs.push_back(M);
+    WalkArgs A; memset(&A, 0, sizeof(A));
+    A.H = H; A.W = W; A.plane = (int64_t)N; A.st = st.data(); A.keys = keys.data(); A.lin = lin.data(); A.comp_start = cs.data(); A.nc = NC;
+    A.total_fg[0] = M;
+    std::vector<unsigned long long> comp_pts(NC + 1, 0), pts_base(NC + 1, 0); std::vector<unsigned> comp_paths(NC + 1, 0), path_base(NC + 1, 0);
+    A.comp_pts = comp_pts.data(); A.comp_paths = comp_paths.data(); A.pts_base = pts_base.data(); A.path_base = path_base.data();
+    for (unsigned c = 0; c < NC; c++) walk_component<false>(A, c);
+    for (unsigned c = 0; c < NC; c++) { pts_base[c + 1] = pts_base[c] + comp_pts[c]; path_base[c + 1] = path_base[c] + comp_paths[c]; }
+    *n_paths = path_base[NC]; *n_pts = (int64_t)pts_base[NC];
+    if (*n_paths + 1 > off_cap || *n_pts > pts_cap) return 1;
+    for (unsigned i = 0; i < M; i++) st[lin[i]] &= (uint8_t)~ST_VIS;
+    std::vector<unsigned long long> desc((size_t)M * 4 + 4); unsigned n_desc = 0;
+    A.desc = desc.data(); A.n_desc = &n_desc; A.desc_cap = M;
+    A.pts[0] = pts_out; A.off[0] = off_out;
+    for (unsigned c = 0; c < NC; c++) walk_component<true>(A, c);
+    for (unsigned d = 0; d < n_desc; d++) {
+        unsigned long long pos = desc[4 * d + 1], lam = desc[4 * d + 2], cnt = desc[4 * d + 3];
+        for (unsigned long long j = 0; j < cnt; j++) { pts_out[2 * (pos + j)] = pts_out[2 * (pos - lam + (j % lam))]; pts_out[2 * (pos + j) + 1] = pts_out[2 * (pos - lam + (j % lam)) + 1]; }
+    }
+    return 0;
+}
