@@ -1,0 +1,216 @@
+// csrc/vec_common.h -- device-side building blocks shared by the vector stages (05, 07, 08, 10, 12).
+#pragma once
+#include "orip_ctx.h"
+#include "vec_serial.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+namespace {   // every TU that includes this header gets its own copy of the kernels (internal linkage)
+
+// ---- rocPRIM wrappers (temporary storage in ctx->tmpF) ----
+template <class T>
+static int vscan_excl(orip_ctx* c, const T* in, T* out, size_t n) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    HIPC(c, c->tmpF.ensure(bytes + 16));
+    HIPC(c, rocprim::exclusive_scan(c->tmpF.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    return 0;
+}
+template <class K, class V>
+static int vsort_pairs(orip_ctx* c, const K* kin, K* kout, const V* vin, V* vout, size_t n, int begin_bit, int end_bit, bool desc = false) {
+    if (n == 0) return 0;
+    size_t bytes = 0;
+    if (!desc) HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+    else HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+    HIPC(c, c->tmpF.ensure(bytes + 16));
+    if (!desc) HIPC(c, rocprim::radix_sort_pairs(c->tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+    else HIPC(c, rocprim::radix_sort_pairs_desc(c->tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+    return 0;
+}
+template <class T>
+static int vread(orip_ctx* c, T* host, const T* dev, size_t n = 1) {
+    HIPC(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- per-polyline features ----
+struct PolyFeat {
+    int32_t x0, y0, x1, y1;     // bbox
+    int32_t sx, sy, ex, ey;     // first / last point (of the OPEN view when open_view)
+    int64_t n;                  // points (of the open view when open_view)
+    float per;                  // numpy pairwise float32 perimeter (KIND 0) or 12:_poly_len (KIND 1)
+    double arc;                 // cv::arcLength (closed flag given by caller), exact double sum
+    uint8_t closed;             // first == last on the ORIGINAL polyline (n >= 2)
+};
+
+// what: bit0 perimeter KIND0, bit1 perimeter KIND1 (hypot), bit2 arcLength closed, bit3 arcLength open, bit4 open view (_ensure_open)
+__global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
+                                                        PolyFeat* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_polys) return;
+    const int32_t* p = pts + 2 * off[i];
+    int64_t n = off[i + 1] - off[i];
+    PolyFeat f;
+    f.closed = (n >= 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) ? 1 : 0;
+    if ((what & 16) && f.closed) n -= 1;
+    f.n = n;
+    int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
+    for (int64_t k = 1; k < n; k++) { int32_t x = p[2 * k], y = p[2 * k + 1]; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+    f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
+    f.sx = p[0]; f.sy = p[1]; f.ex = p[2 * (n - 1)]; f.ey = p[2 * (n - 1) + 1];
+    f.per = 0.f; f.arc = 0.0;
+    if (what & 1) f.per = vs::pairwise_seglen_sum<0>(p, n);
+    if (what & 2) f.per = vs::pairwise_seglen_sum<1>(p, n);
+    if (what & 4) f.arc = vs::arc_length(p, n, true);
+    if (what & 8) f.arc = vs::arc_length(p, n, false);
+    out[i] = f;
+}
+
+// ---- greedy nearest-neighbour ordering (07:55-79 / 08:223-248 / 10:69-97), one 1024-thread block per list ----
+// rule07: closed contours are entered at their start only and the cursor returns to their start (07:60-62, 80-83).
+struct NNEnds { int32_t sx, sy, ex, ey; uint8_t closed; };
+__device__ __forceinline__ float nn_d2(int32_t ax, int32_t ay, int32_t bx, int32_t by) {
+    float dx = __fsub_rn((float)ax, (float)bx), dy = __fsub_rn((float)ay, (float)by);
+    return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+}
+__global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ ends, int n, int seed, int rule07, uint8_t* __restrict__ used,
+                                                     int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    __shared__ unsigned long long wbest[16];
+    __shared__ int cxs, cys;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) used[i] = (i == seed);
+    if (tid == 0) {
+        order[0] = seed; flips[0] = 0;
+        NNEnds e = ends[seed];
+        if (rule07 && e.closed) { cxs = e.sx; cys = e.sy; } else { cxs = e.ex; cys = e.ey; }
+    }
+    __syncthreads();
+    for (int step = 1; step < n; step++) {
+        const int cx = cxs, cy = cys;
+        unsigned long long best = ~0ULL;
+        for (int i = tid; i < n; i += 1024) {
+            if (used[i]) continue;
+            NNEnds e = ends[i];
+            float ds = nn_d2(e.sx, e.sy, cx, cy);
+            float v = ds;
+            if (!(rule07 && e.closed)) { float de = nn_d2(e.ex, e.ey, cx, cy); if (!(ds <= de)) v = de; }
+            unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
+            if (key < best) best = key;
+        }
+        for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(best, o, 64); if (t < best) best = t; }
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = wbest[0];
+            for (int w = 1; w < 16; w++) if (wbest[w] < b) b = wbest[w];
+            int bi = (int)(b & 0xffffffffu);
+            NNEnds e = ends[bi];
+            float ds = nn_d2(e.sx, e.sy, cx, cy), de = nn_d2(e.ex, e.ey, cx, cy);
+            bool cl = rule07 && e.closed;
+            bool flip = cl ? false : !(ds <= de);
+            used[bi] = 1; order[step] = bi; flips[step] = flip ? 1 : 0;
+            if (cl) { cxs = e.sx; cys = e.sy; }
+            else if (flip) { cxs = e.sx; cys = e.sy; } else { cxs = e.ex; cys = e.ey; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- descriptor-driven gather: output polyline k = src points [begin[k], begin[k]+len[k]) (reversed if rev[k]) ----
+struct GatherDesc { int64_t begin; int64_t len; int32_t rev; int32_t pad; };
+__global__ __launch_bounds__(256) void k_gather_lens(const GatherDesc* __restrict__ d, int64_t n, int64_t* __restrict__ lens) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) lens[i] = d[i].len;
+    if (i == n) lens[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_gather_pts(const GatherDesc* __restrict__ d, int64_t n, const int32_t* __restrict__ src,
+                                                     const int64_t* __restrict__ out_off, int32_t* __restrict__ dst) {
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        GatherDesc g = d[k];
+        const int2* s = reinterpret_cast<const int2*>(src) + g.begin;
+        int2* o = reinterpret_cast<int2*>(dst) + out_off[k];
+        for (int64_t j = threadIdx.x; j < g.len; j += 256) o[j] = g.rev ? s[g.len - 1 - j] : s[j];
+    }
+}
+// Builds dst (DPolys) from descriptors (device array of n descs).  lens/off scratch in ctx->tmpE.
+static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* src, DPolys& dst) {
+    dst.n = n; dst.total = 0;
+    HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
+    if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream)); return 0; }
+    HIPC(c, c->tmpE.ensure((size_t)(n + 1) * 8 + 64));
+    hipLaunchKernelGGL(k_gather_lens, dim3(cdiv(n + 1, 256)), dim3(256), 0, c->stream, d, n, c->tmpE.as<int64_t>());
+    ORIP_TRY(vscan_excl<int64_t>(c, c->tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
+    int64_t total = 0;
+    ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
+    dst.total = total;
+    HIPC(c, dst.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
+    hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, c->stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>());
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// order/flip -> descriptors over a source list
+__global__ __launch_bounds__(256) void k_desc_from_order(const int64_t* __restrict__ off, const int32_t* __restrict__ order, const uint8_t* __restrict__ flips,
+                                                          int64_t n, int open_view, const PolyFeat* __restrict__ feat, GatherDesc* __restrict__ d) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    int i = order ? order[k] : (int)k;
+    GatherDesc g; g.begin = off[i]; g.len = open_view ? feat[i].n : (off[i + 1] - off[i]); g.rev = flips ? flips[k] : 0; g.pad = 0;
+    d[k] = g;
+}
+
+// argmax with first-max tie-break over a float / double field of PolyFeat (seed of the greedy orders); tiny: single block
+__global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict__ f, int n, int use_arc, int* __restrict__ out) {
+    __shared__ double bv[1024]; __shared__ int bi[1024];
+    double v = -1.0; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) { double x = use_arc ? f[i].arc : (double)f[i].per; if (x > v) { v = x; idx = i; } }
+    bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            double o = bv[threadIdx.x + s]; int oi = bi[threadIdx.x + s];
+            if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = bi[0];
+}
+__global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restrict__ f, int64_t n, int rule07, const int64_t* __restrict__ off,
+                                                         const int32_t* __restrict__ pts, NNEnds* __restrict__ e) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    NNEnds q; q.sx = f[i].sx; q.sy = f[i].sy; q.ex = f[i].ex; q.ey = f[i].ey; q.closed = f[i].closed;
+    if (rule07 && f[i].closed) {   // _ends (07:12-17): a closed contour ends at its second-to-last point
+        int64_t m = off[i + 1] - off[i];
+        if (m > 1) { const int32_t* p = pts + 2 * off[i]; q.ex = p[2 * (m - 2)]; q.ey = p[2 * (m - 2) + 1]; }
+    }
+    e[i] = q;
+}
+
+// Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
+static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
+    int64_t n = src.n;
+    if (n == 0) { dst.n = 0; dst.total = 0; HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream)); return 0; }
+    if (n > 0x7fffffff) ORIP_FAIL(c, "too many polylines");
+    HIPC(c, c->vtmp[6].ensure((size_t)n * (sizeof(PolyFeat) + sizeof(NNEnds) + sizeof(GatherDesc) + 4 + 2) + 256));
+    PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
+    NNEnds* ends = (NNEnds*)(feat + n);
+    GatherDesc* desc = (GatherDesc*)(ends + n);
+    int32_t* order = (int32_t*)(desc + n);
+    uint8_t* flips = (uint8_t*)(order + n); uint8_t* used = flips + n;
+    int what = kind == 7 ? 4 : (kind == 8 ? 1 : 8);
+    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, c->stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, what, feat);
+    hipLaunchKernelGGL(k_ends_from_feat, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, feat, n, kind == 7 ? 1 : 0, src.off.as<int64_t>(), src.pts.as<int32_t>(), ends);
+    int* d_seed = c->flags.as<int>() + 32;
+    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, c->stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
+    int seed = 0;
+    ORIP_TRY(vread(c, &seed, d_seed));
+    { ProfScope ps(c, "k_greedy_nn"); hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, c->stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips); }
+    hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
+    HIPC(c, hipGetLastError());
+    return vgather(c, desc, n, src.pts.as<int32_t>(), dst);
+}
+
+}  // namespace

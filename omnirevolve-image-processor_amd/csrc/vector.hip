@@ -1,8 +1,183 @@
-// csrc/vector.hip -- stages 05 / 07 / 08 / 10 / 12 (placeholder entry points; filled in stage by stage)
-#include "orip_ctx.h"
-extern "C" int orip_scale_vectors(orip_ctx* c, int, float, float, float, float) { ORIP_FAIL(c, "not implemented yet"); }
-extern "C" int orip_sort_contours(orip_ctx* c, int) { ORIP_FAIL(c, "not implemented yet"); }
+// csrc/vector.hip -- stage 05 (_scale_one, 05:82-96), stage 07 (reorder_one_color, 07:19-95) and
+// stage 12 (_build_ops_for_layer, 12:85-187) on gfx950.
+#include "vec_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Stage 05: pts.astype(f32) @ S.T + T in float32, truncation to int32.  8 B in + 8 B out per point.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, int2* __restrict__ out, int64_t n, float sx, float sy, float dx, float dy) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int2 p = in[i];
+        float x = __fadd_rn(__fmul_rn((float)p.x, sx), dx), y = __fadd_rn(__fmul_rn((float)p.y, sy), dy);
+        out[i] = make_int2((int)x, (int)y);
+    }
+}
+
+extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
+    if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
+    D.n = S.n; D.total = S.total;
+    HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
+    HIPC(c, D.pts.ensure((size_t)std::max<int64_t>(S.total, 1) * 8 + 64));
+    if (S.n == 0) { HIPC(c, hipMemsetAsync(D.off.p, 0, 8, c->stream)); return 0; }
+    HIPC(c, hipMemcpyAsync(D.off.p, S.off.p, (size_t)(S.n + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (S.total) {
+        ProfScope ps(c, "k_scale_pts");
+        hipLaunchKernelGGL(k_scale_pts, dim3((unsigned)std::min<int64_t>(cdiv(S.total, 256), 8192)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const int2*>(S.pts.p), reinterpret_cast<int2*>(D.pts.p), S.total, sx, sy, dx, dy);
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
+    if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    return vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 12.  All positions are integers (line ends, tap centres), so every hypot comparison of the
+// reference is evaluated on exact squared distances; ties resolve in the reference's scan order
+// (line k start, line k end, ..., then taps).  One 1024-thread block per layer.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long d2i(long long ax, long long ay, long long bx, long long by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
+
+__global__ __launch_bounds__(1024) void k_plot_order(const PolyFeat* __restrict__ lf, int nl, const int32_t* __restrict__ taps, int nt, double R,
+                                                      uint8_t* __restrict__ alive_l, uint8_t* __restrict__ alive_t, int32_t* __restrict__ ops, int* __restrict__ n_ops_out) {
+    __shared__ unsigned long long wb[16];
+    __shared__ long long px, py; __shared__ int nops, cursor, found;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nl; i += 1024) alive_l[i] = 1;
+    for (int i = tid; i < nt; i += 1024) alive_t[i] = 1;
+    if (tid == 0) { px = 0; py = 0; nops = 0; }
+    __syncthreads();
+    auto emit_line = [&](int k, int flip) { int o = nops++; ops[5 * o] = 0; ops[5 * o + 1] = k; ops[5 * o + 2] = flip; ops[5 * o + 3] = 0; ops[5 * o + 4] = 0; };
+    auto emit_tap = [&](int t) { int o = nops++; ops[5 * o] = 1; ops[5 * o + 1] = -1; ops[5 * o + 2] = 0; ops[5 * o + 3] = taps[2 * t]; ops[5 * o + 4] = taps[2 * t + 1]; };
+    auto block_min = [&](unsigned long long v) -> unsigned long long {
+        for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(v, o, 64); if (t < v) v = t; }
+        __syncthreads();
+        if ((tid & 63) == 0) wb[tid >> 6] = v;
+        __syncthreads();
+        unsigned long long b = wb[0];
+        for (int w = 1; w < 16; w++) if (wb[w] < b) b = wb[w];
+        return b;
+    };
+    // drain (12:120-127, 174-181): single forward pass over the alive taps, the cursor follows each drained tap
+    auto drain = [&]() {
+        if (tid == 0) cursor = 0;
+        __syncthreads();
+        while (true) {
+            int cur = cursor; long long x = px, y = py;
+            unsigned long long best = ~0ULL;
+            for (int t = cur + tid; t < nt; t += 1024) {
+                if (!alive_t[t]) continue;
+                long long q = d2i(x, y, taps[2 * t], taps[2 * t + 1]);
+                if (sqrt((double)q) <= R) { best = (unsigned long long)t; break; }   // smallest index of this lane's stride
+            }
+            unsigned long long b = block_min(best);
+            if (b == ~0ULL) break;
+            if (tid == 0) { int t = (int)b; emit_tap(t); alive_t[t] = 0; px = taps[2 * t]; py = taps[2 * t + 1]; cursor = t + 1; }
+            __syncthreads();
+        }
+        __syncthreads();
+    };
+    if (nl > 0) {
+        // first = longest line (first maximum), entered from the end nearer to (0,0) (strict <)
+        unsigned long long best = ~0ULL;
+        for (int k = tid; k < nl; k += 1024) {
+            unsigned long long key = ((unsigned long long)(~__float_as_uint(lf[k].per)) << 32) | (unsigned)k;   // per >= 0: larger per -> smaller key
+            if (key < best) best = key;
+        }
+        unsigned long long b = block_min(best);
+        if (tid == 0) {
+            int k = (int)(b & 0xffffffffu);
+            PolyFeat f = lf[k];
+            int flip = d2i(0, 0, f.ex, f.ey) < d2i(0, 0, f.sx, f.sy);
+            emit_line(k, flip); alive_l[k] = 0;
+            if (flip) { px = f.sx; py = f.sy; } else { px = f.ex; py = f.ey; }
+        }
+        __syncthreads();
+        drain();
+    } else if (nt > 0) {
+        unsigned long long best = ~0ULL;
+        for (int t = tid; t < nt; t += 1024) {
+            unsigned long long key = ((unsigned long long)d2i(0, 0, taps[2 * t], taps[2 * t + 1]) << 32) | (unsigned)t;
+            if (key < best) best = key;
+        }
+        unsigned long long b = block_min(best);
+        if (tid == 0) { int t = (int)(b & 0xffffffffu); emit_tap(t); alive_t[t] = 0; px = taps[2 * t]; py = taps[2 * t + 1]; }
+        __syncthreads();
+    }
+    const int total = nl + nt;
+    while (true) {
+        __syncthreads();
+        if (nops >= total) break;
+        long long x = px, y = py;
+        unsigned long long best = ~0ULL;
+        for (int k = tid; k < nl; k += 1024) {
+            if (!alive_l[k]) continue;
+            unsigned long long k1 = ((unsigned long long)d2i(x, y, lf[k].sx, lf[k].sy) << 32) | (unsigned)(2 * k);
+            unsigned long long k2 = ((unsigned long long)d2i(x, y, lf[k].ex, lf[k].ey) << 32) | (unsigned)(2 * k + 1);
+            if (k1 < best) best = k1;
+            if (k2 < best) best = k2;
+        }
+        for (int t = tid; t < nt; t += 1024) {
+            if (!alive_t[t]) continue;
+            unsigned long long kt = ((unsigned long long)d2i(x, y, taps[2 * t], taps[2 * t + 1]) << 32) | (unsigned)(2 * nl + t);
+            if (kt < best) best = kt;
+        }
+        unsigned long long b = block_min(best);
+        if (b == ~0ULL) break;
+        unsigned idx = (unsigned)(b & 0xffffffffu);
+        bool is_line = idx < (unsigned)(2 * nl);
+        if (tid == 0) {
+            if (is_line) {
+                int k = idx >> 1, flip = idx & 1;
+                emit_line(k, flip); alive_l[k] = 0;
+                if (flip) { px = lf[k].sx; py = lf[k].sy; } else { px = lf[k].ex; py = lf[k].ey; }
+            } else {
+                int t = idx - 2 * nl;
+                emit_tap(t); alive_t[t] = 0; px = taps[2 * t]; py = taps[2 * t + 1];
+            }
+        }
+        __syncthreads();
+        if (is_line) drain();
+    }
+    if (tid == 0) *n_ops_out = nops;
+    (void)found;
+}
+
+extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t* n_ops) {
+    if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    DPolys& L = c->polys[ORIP_SLOT_LINES_CROSS][layer]; DTaps& T = c->taps[ORIP_TAPS_CROSS][layer];
+    int64_t nl = L.n, nt = T.n;
+    c->n_ops[layer] = 0; *n_ops = 0;
+    if (nl + nt == 0) return 0;
+    if (nl + nt > 0x3fffffff) ORIP_FAIL(c, "too many ops");
+    HIPC(c, c->vtmp[6].ensure((size_t)std::max<int64_t>(nl, 1) * sizeof(PolyFeat) + (size_t)(nl + nt) + 256));
+    PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
+    uint8_t* alive_l = (uint8_t*)(feat + std::max<int64_t>(nl, 1)); uint8_t* alive_t = alive_l + nl;
+    HIPC(c, c->ops[layer].ensure((size_t)(nl + nt) * 20 + 64));
+    HIPC(c, T.xy.ensure(64));
+    if (nl) hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nl, 128)), dim3(128), 0, c->stream, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, 2, feat);
+    int* d_n = c->flags.as<int>() + 40;
+    { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, c->stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
+    HIPC(c, hipGetLastError());
+    int h = 0;
+    ORIP_TRY(vread(c, &h, d_n));
+    c->n_ops[layer] = h; *n_ops = h;
+    return 0;
+}
+
+extern "C" int orip_get_ops(orip_ctx* c, int layer, int32_t* ops5) {
+    if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    if (!c->n_ops[layer]) return 0;
+    HIPC(c, hipMemcpyAsync(ops5, c->ops[layer].p, (size_t)c->n_ops[layer] * 20, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// placeholders until vector08.hip / vector10.hip land
+#ifndef ORIP_HAVE_08
 extern "C" int orip_dedup_layer(orip_ctx* c, int, const orip_params08*) { ORIP_FAIL(c, "not implemented yet"); }
-extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t*, int, const orip_params10*) { ORIP_FAIL(c, "not implemented yet"); }
-extern "C" int orip_plot_order(orip_ctx* c, int, double, int64_t*) { ORIP_FAIL(c, "not implemented yet"); }
-extern "C" int orip_get_ops(orip_ctx* c, int, int32_t*) { ORIP_FAIL(c, "not implemented yet"); }
+#endif

@@ -1,0 +1,334 @@
+// csrc/vector10.hip -- stage 10 (10_dedup_cross_basic.py main, 10:212-278) on gfx950.
+// Layers are visited dark -> light against one cumulative forbidden raster (10:215,236-267):
+//   cut      : every polyline is walked in ~1 px steps (10:142-177); all step points of all polylines of the layer are
+//              evaluated in parallel against the raster as left by the PREVIOUS layers (the raster does not change while
+//              a layer is cut), runs of >= 2 free points become the new polylines
+//   jumps    : _split_on_long_jumps (10:49-63) is the identity on cut output (consecutive points are <= 1 px apart)
+//   taps     : _tiny_and_taps (10:99-118) with cv::minEnclosingCircle only where the bbox cannot decide
+//   reorder  : _reorder_for_travel (10:69-97) -> k_greedy_nn
+//   paint    : cv2.polylines(thickness=120) over vertex chains whose consecutive vertices are <= sqrt(2) apart equals, on
+//              the integer grid, the union of radius-60 discs at the vertices (DESIGN.md "stage 10 paint"), evaluated as an
+//              exact two-pass disc dilation (row pass with wave ballots, column pass)
+//   taps seq : sequential accept + immediate stamp (10:259-267) as one workgroup walking the tap list
+#include "vec_common.h"
+#define ORIP_PAD 64
+
+// ---- cut ----
+__global__ __launch_bounds__(256) void k_cut_counts(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step_px,
+                                                     unsigned* __restrict__ cnt, uint8_t* __restrict__ first_of_poly) {
+    // one block per polyline (grid-stride), threads over its points
+    for (int64_t p = blockIdx.x; p < n_polys; p += gridDim.x) {
+        int64_t b = off[p], e = off[p + 1];
+        for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+            unsigned c = 0; uint8_t f = 0;
+            if (e - b >= 2) {
+                if (i == b) { c = 1; f = 1; }
+                else {
+                    float vx = (float)pts[2 * i] - (float)pts[2 * i - 2], vy = (float)pts[2 * i + 1] - (float)pts[2 * i - 1];
+                    double L = (double)(float)sqrt((double)vx * (double)vx + (double)vy * (double)vy);
+                    if (L > 1e-6) { double q = ceil(L / fmax(1.0, step_px)); c = (unsigned)fmax(1.0, q); }
+                }
+            }
+            cnt[i] = c; first_of_poly[i] = f;
+        }
+    }
+}
+
+// slot s -> (point index i, step k): i = upper_bound(base, s) - 1
+__device__ __forceinline__ int64_t ub_u32(const unsigned* a, int64_t n, unsigned v) {   // first index with a[idx] > v
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_cut_slots(const int32_t* __restrict__ pts, const unsigned* __restrict__ cnt, const unsigned* __restrict__ base, int64_t n_pts,
+                                                    const uint8_t* __restrict__ first_of_poly, unsigned n_slots, const u8* __restrict__ forb, int H, int W,
+                                                    int2* __restrict__ spt, uint8_t* __restrict__ sflag /* bit0 free, bit1 poly start */) {
+    unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slots) return;
+    int64_t i = ub_u32(base, n_pts, s) - 1;
+    while (cnt[i] == 0) i--;            // base[] repeats over zero-count points; the owner is the last one with cnt > 0 and base <= s
+    float qx, qy; uint8_t fl = 0;
+    if (first_of_poly[i]) { qx = (float)pts[2 * i]; qy = (float)pts[2 * i + 1]; fl = 2; }
+    else {
+        unsigned k = s - base[i] + 1, n = cnt[i];
+        float p0x = (float)pts[2 * i - 2], p0y = (float)pts[2 * i - 1];
+        float vx = __fsub_rn((float)pts[2 * i], p0x), vy = __fsub_rn((float)pts[2 * i + 1], p0y);
+        float t = (float)((double)k / (double)n);
+        qx = __fadd_rn(p0x, __fmul_rn(vx, t)); qy = __fadd_rn(p0y, __fmul_rn(vy, t));
+    }
+    long long xi = vs::round_half_even((double)qx), yi = vs::round_half_even((double)qy);
+    bool blocked = (yi >= 0 && yi < H && xi >= 0 && xi < W) && forb[(size_t)yi * W + xi] != 0;
+    if (!blocked) fl |= 1;
+    spt[s] = make_int2((int)qx, (int)qy);
+    sflag[s] = fl;
+}
+__global__ __launch_bounds__(256) void k_run_starts(const uint8_t* __restrict__ sflag, unsigned n, unsigned* __restrict__ start) {
+    unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    uint8_t f = sflag[s];
+    start[s] = ((f & 1) && ((f & 2) || s == 0 || !(sflag[s - 1] & 1))) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_run_accum(const uint8_t* __restrict__ sflag, const unsigned* __restrict__ start, const unsigned* __restrict__ start_scan,
+                                                    unsigned n, unsigned* __restrict__ rlen, unsigned* __restrict__ rbegin) {
+    unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    if (!(sflag[s] & 1)) return;
+    unsigned rid = start_scan[s] + start[s] - 1;      // inclusive scan - 1
+    atomicAdd(&rlen[rid], 1u);
+    if (start[s]) rbegin[rid] = s;
+}
+__global__ __launch_bounds__(256) void k_run_keep(const unsigned* __restrict__ rlen, unsigned n_runs, unsigned min_len, unsigned* __restrict__ keep) {
+    unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_runs) keep[r] = rlen[r] >= min_len ? 1u : 0u;
+    if (r == n_runs) keep[r] = 0;
+}
+__global__ __launch_bounds__(256) void k_run_desc(const unsigned* __restrict__ rlen, const unsigned* __restrict__ rbegin, const unsigned* __restrict__ keep,
+                                                   const unsigned* __restrict__ keep_scan, unsigned n_runs, GatherDesc* __restrict__ d) {
+    unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_runs || !keep[r]) return;
+    GatherDesc g; g.begin = rbegin[r]; g.len = rlen[r]; g.rev = 0; g.pad = 0;
+    d[keep_scan[r]] = g;
+}
+
+// Shared by stage 08-A and stage 10: turn per-slot flags (bit0 accepted, bit1 sequence start) + points into a DPolys of runs with >= 2 points
+int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst) {
+    dst.n = 0; dst.total = 0;
+    HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream));
+    if (n_slots == 0) return 0;
+    HIPC(c, c->vtmp[7].ensure((size_t)n_slots * 8 + 64));
+    unsigned* start = c->vtmp[7].as<unsigned>(); unsigned* start_scan = start + n_slots;
+    hipLaunchKernelGGL(k_run_starts, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, sflag, n_slots, start);
+    ORIP_TRY(vscan_excl<unsigned>(c, start, start_scan, n_slots));
+    unsigned a[2];
+    ORIP_TRY(vread(c, &a[0], start_scan + (n_slots - 1)));
+    ORIP_TRY(vread(c, &a[1], start + (n_slots - 1)));
+    unsigned n_runs = a[0] + a[1];
+    if (n_runs == 0) return 0;
+    HIPC(c, c->vtmp[8].ensure((size_t)(n_runs + 1) * 16 + (size_t)n_runs * sizeof(GatherDesc) + 256));
+    unsigned* rlen = c->vtmp[8].as<unsigned>(); unsigned* rbegin = rlen + (n_runs + 1); unsigned* keep = rbegin + (n_runs + 1); unsigned* keep_scan = keep + (n_runs + 1);
+    GatherDesc* desc = (GatherDesc*)(keep_scan + (n_runs + 1) + 2);
+    HIPC(c, hipMemsetAsync(rlen, 0, (size_t)(n_runs + 1) * 4, c->stream));
+    hipLaunchKernelGGL(k_run_accum, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, sflag, start, start_scan, n_slots, rlen, rbegin);
+    hipLaunchKernelGGL(k_run_keep, dim3(cdiv(n_runs + 1, 256)), dim3(256), 0, c->stream, rlen, n_runs, 2u, keep);
+    ORIP_TRY(vscan_excl<unsigned>(c, keep, keep_scan, (size_t)n_runs + 1));
+    unsigned n_keep = 0;
+    ORIP_TRY(vread(c, &n_keep, keep_scan + n_runs));
+    if (n_keep == 0) return 0;
+    hipLaunchKernelGGL(k_run_desc, dim3(cdiv(n_runs, 256)), dim3(256), 0, c->stream, rlen, rbegin, keep, keep_scan, n_runs, desc);
+    HIPC(c, hipGetLastError());
+    return vgather(c, desc, n_keep, reinterpret_cast<const int32_t*>(spt), dst);
+}
+
+// ---- _tiny_and_taps (10:99-118) ----
+// cls: 0 drop, 1 tap, 2 keep
+__global__ __launch_bounds__(128) void k_tiny_taps10(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params10 P,
+                                                      unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_polys) return;
+    if (i == n_polys) { is_tap[i] = 0; is_keep[i] = 0; return; }
+    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
+    int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
+    for (int64_t k = 1; k < n; k++) { x0 = min(x0, p[2 * k]); x1 = max(x1, p[2 * k]); y0 = min(y0, p[2 * k + 1]); y1 = max(y1, p[2 * k + 1]); }
+    unsigned tap = 0, keep = 0;
+    double big = fmax(P.tap_diam, P.min_keep) + 2.0;
+    if ((double)max(x1 - x0, y1 - y0) > big) keep = 1;      // enclosing diameter >= bbox extent > both thresholds: no circle needed
+    else {
+        float cx, cy, r; vs::min_enclosing_circle(p, n, cx, cy, r);
+        double d = 2.0 * (double)r;
+        if (d <= P.tap_diam) {
+            double per = vs::arc_length(p, n, false);
+            if (per <= P.tap_max_per && n <= (int64_t)P.tap_max_v) { tap = 1; tap_xy[i] = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy)); }
+        }
+        if (!tap && d >= P.min_keep) keep = 1;
+    }
+    is_tap[i] = tap; is_keep[i] = keep;
+}
+__global__ __launch_bounds__(256) void k_compact_sel(const unsigned* __restrict__ flag, const unsigned* __restrict__ scan, int64_t n, const int64_t* __restrict__ off,
+                                                      GatherDesc* __restrict__ d, const int2* __restrict__ tap_xy, int2* __restrict__ taps_out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    if (d) { GatherDesc g; g.begin = off[i]; g.len = off[i + 1] - off[i]; g.rev = 0; g.pad = 0; d[scan[i]] = g; }
+    if (taps_out) taps_out[scan[i]] = tap_xy[i];
+}
+
+// ---- paint: exact disc dilation of the vertex set ----
+__global__ __launch_bounds__(256) void k_seed_mark(const int2* __restrict__ pts, int64_t n, u8* __restrict__ seeds, int Hp, int Wp) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int x = pts[i].x + ORIP_PAD, y = pts[i].y + ORIP_PAD;
+    if (x >= 0 && x < Wp && y >= 0 && y < Hp) seeds[(size_t)y * Wp + x] = 1;
+}
+// one wave per padded row: horizontal distance to the nearest seed of the row, capped at 255
+__global__ __launch_bounds__(64) void k_row_hdist(const u8* __restrict__ seeds, u8* __restrict__ hd, int Hp, int Wp) {
+    int y = blockIdx.x; const int lane = threadIdx.x;
+    const u8* s = seeds + (size_t)y * Wp; u8* o = hd + (size_t)y * Wp;
+    int nch = (Wp + 63) >> 6;
+    int last = -100000;
+    for (int c = 0; c < nch; c++) {
+        int x = (c << 6) + lane;
+        bool sd = x < Wp && s[x];
+        unsigned long long b = __ballot(sd);
+        unsigned long long m = b & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
+        int pos = m ? ((c << 6) + 63 - __clzll((long long)m)) : last;
+        int d = x - pos;
+        if (x < Wp) o[x] = (u8)min(d, 255);
+        if (b) last = (c << 6) + 63 - __clzll((long long)b);
+    }
+    int nxt = 100000000;
+    for (int c = nch - 1; c >= 0; c--) {
+        int x = (c << 6) + lane;
+        bool sd = x < Wp && s[x];
+        unsigned long long b = __ballot(sd);
+        unsigned long long m = b & (~0ULL << lane);
+        int pos = m ? ((c << 6) + __ffsll((long long)m) - 1) : nxt;
+        int d = pos - x;
+        if (x < Wp) { int cur = o[x]; o[x] = (u8)min(cur, min(d, 255)); }
+        if (b) nxt = (c << 6) + __ffsll((long long)b) - 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_col_cover(const u8* __restrict__ hd, u8* __restrict__ forb, int H, int W, int Hp, int Wp, int r) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    if (forb[o]) return;
+    const int r2 = r * r;
+    bool cov = false;
+    for (int dy = -r; dy <= r && !cov; dy++) {
+        int yy = y + dy + ORIP_PAD;
+        if (yy < 0 || yy >= Hp) continue;
+        int h = hd[(size_t)yy * Wp + x + ORIP_PAD];
+        if (h * h + dy * dy <= r2) cov = true;
+    }
+    if (cov) forb[o] = 255;
+}
+__global__ __launch_bounds__(256) void k_stamp_discs(const int2* __restrict__ taps, int n, int r, u8* __restrict__ forb, int H, int W) {
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        int cx = taps[t].x, cy = taps[t].y; int side = 2 * r + 1;
+        for (int i = threadIdx.x; i < side * side; i += 256) {
+            int dx = i % side - r, dy = i / side - r;
+            int x = cx + dx, y = cy + dy;
+            if (x < 0 || x >= W || y < 0 || y >= H) continue;
+            if (dx * dx + dy * dy <= r * r) forb[(size_t)y * W + x] = 255;
+        }
+    }
+}
+// sequential taps (10:259-267): accept iff the centre is free of the raster AND of every disc accepted before it in this layer
+__global__ __launch_bounds__(1024) void k_taps_sequential(const int2* __restrict__ seq, int n, int r, const u8* __restrict__ forb, int H, int W,
+                                                           int2* __restrict__ acc, int* __restrict__ n_acc_out) {
+    __shared__ int nacc, hit;
+    if (threadIdx.x == 0) nacc = 0;
+    __syncthreads();
+    const long long r2 = (long long)r * r;
+    for (int i = 0; i < n; i++) {
+        int x = seq[i].x, y = seq[i].y;
+        bool inside = (y >= 0 && y < H && x >= 0 && x < W);
+        if (threadIdx.x == 0) hit = (inside && forb[(size_t)y * W + x] != 0) ? 1 : 0;
+        __syncthreads();
+        if (inside && !hit) {
+            int na = nacc;
+            for (int j = threadIdx.x; j < na; j += 1024) {
+                long long dx = acc[j].x - x, dy = acc[j].y - y;
+                if (dx * dx + dy * dy <= r2) hit = 1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && !hit) { acc[nacc] = make_int2(x, y); nacc++; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_acc_out = nacc;
+}
+
+extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers, const orip_params10* prm) {
+    if (!prm || n_layers < 0 || n_layers > ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
+    const orip_params10 P = *prm;
+    const int W = P.W, H = P.H;
+    if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
+    if (P.max_jump < 4.0) ORIP_FAIL(c, "max_join_jump_px < 4 is not supported (cut output is assumed jump-free)");
+    const int Wp = W + 2 * ORIP_PAD, Hp = H + 2 * ORIP_PAD;
+    const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
+    const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));
+    if (rad_lines > ORIP_PAD - 2 || rad_taps > 200) ORIP_FAIL(c, "brush radius %d/%d too large for the padded raster", rad_lines, rad_taps);
+    HIPC(c, c->canvas.ensure((size_t)W * H + 64));
+    u8* forb = c->canvas.as<u8>();
+    HIPC(c, hipMemsetAsync(forb, 0, (size_t)W * H, c->stream));
+    HIPC(c, c->vtmp[9].ensure((size_t)Wp * Hp * 2 + 64));
+    u8* seeds = c->vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp;
+    for (int li = 0; li < n_layers; li++) {
+        const int layer = order[li];
+        if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+        DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
+        DTaps& Tin = c->taps[ORIP_TAPS_INTRA][layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
+        // ---- 1) cut
+        DPolys cut;   // temporaries owned by this call
+        struct Guard { DPolys* a; DPolys* b; ~Guard() { a->off.release(); a->pts.release(); b->off.release(); b->pts.release(); } };
+        DPolys keepl; Guard guard{&cut, &keepl};
+        cut.n = 0; cut.total = 0;
+        if (Lin.n > 0 && Lin.total > 0) {
+            if (Lin.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
+            HIPC(c, c->vtmp[0].ensure((size_t)(Lin.total + 1) * 9 + 64));
+            unsigned* cnt = c->vtmp[0].as<unsigned>(); unsigned* base = cnt + (Lin.total + 1); uint8_t* fop = (uint8_t*)(base + (Lin.total + 1));
+            HIPC(c, hipMemsetAsync(cnt + Lin.total, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_cut_counts, dim3((unsigned)std::min<int64_t>(Lin.n, 65535)), dim3(256), 0, c->stream, Lin.off.as<int64_t>(), Lin.pts.as<int32_t>(), Lin.n, P.step_px, cnt, fop);
+            ORIP_TRY(vscan_excl<unsigned>(c, cnt, base, (size_t)Lin.total + 1));
+            unsigned n_slots = 0;
+            ORIP_TRY(vread(c, &n_slots, base + Lin.total));
+            if (n_slots) {
+                HIPC(c, c->vtmp[1].ensure((size_t)n_slots * 9 + 64));
+                int2* spt = c->vtmp[1].as<int2>(); uint8_t* sflag = (uint8_t*)(spt + n_slots);
+                { ProfScope ps(c, "k_cut_slots"); hipLaunchKernelGGL(k_cut_slots, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, Lin.pts.as<int32_t>(), cnt, base, Lin.total, fop, n_slots, forb, H, W, spt, sflag); }
+                ORIP_TRY(orip_runs_to_polys(c, spt, sflag, n_slots, cut));
+            }
+        }
+        // ---- 2,3) jumps are the identity; tiny lines -> taps / dropped
+        int64_t n_tap_lines = 0;
+        keepl.n = 0; keepl.total = 0;
+        HIPC(c, c->vtmp[2].ensure((size_t)(cut.n + 1) * (16 + 8 + sizeof(GatherDesc)) + 256));
+        unsigned* is_tap = c->vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (cut.n + 1); unsigned* tap_scan = is_keep + (cut.n + 1); unsigned* keep_scan = tap_scan + (cut.n + 1);
+        int2* tap_xy = (int2*)(keep_scan + (cut.n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (cut.n + 1));
+        int64_t n_seq = Tin.n;
+        if (cut.n > 0) {
+            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, c->stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, is_tap, is_keep, tap_xy);
+            ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
+            ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));
+            unsigned a = 0, b = 0;
+            ORIP_TRY(vread(c, &a, tap_scan + cut.n)); ORIP_TRY(vread(c, &b, keep_scan + cut.n));
+            n_tap_lines = a;
+            if (b) {
+                hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, c->stream, is_keep, keep_scan, cut.n, cut.off.as<int64_t>(), kd, (const int2*)nullptr, (int2*)nullptr);
+                ORIP_TRY(vgather(c, kd, b, cut.pts.as<int32_t>(), keepl));
+            }
+        }
+        // taps_seq = taps_in + taps_from_lines
+        n_seq = Tin.n + n_tap_lines;
+        HIPC(c, c->vtmp[3].ensure((size_t)(n_seq + 1) * 16 + 64));
+        int2* seq = c->vtmp[3].as<int2>(); int2* acc = seq + (n_seq + 1);
+        if (Tin.n) HIPC(c, hipMemcpyAsync(seq, Tin.xy.p, (size_t)Tin.n * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (n_tap_lines) hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, c->stream, is_tap, tap_scan, cut.n, cut.off.as<int64_t>(), (GatherDesc*)nullptr, tap_xy, seq + Tin.n);
+        // ---- 4) reorder
+        ORIP_TRY(vreorder(c, keepl, Lout, 10));
+        // ---- 5) paint lines (exact disc dilation of all vertices)
+        if (Lout.total > 0) {
+            HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, c->stream));
+            hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, c->stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp);
+            { ProfScope ps(c, "k_row_hdist"); hipLaunchKernelGGL(k_row_hdist, dim3(Hp), dim3(64), 0, c->stream, seeds, hd, Hp, Wp); }
+            { ProfScope ps(c, "k_col_cover"); hipLaunchKernelGGL(k_col_cover, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), 0, c->stream, hd, forb, H, W, Hp, Wp, rad_lines); }
+        }
+        // ---- 6) sequential taps
+        Tout.n = 0;
+        HIPC(c, Tout.xy.ensure((size_t)std::max<int64_t>(n_seq, 1) * 8 + 64));
+        if (n_seq > 0) {
+            int* d_n = c->flags.as<int>() + 44;
+            { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, c->stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
+            int na = 0;
+            ORIP_TRY(vread(c, &na, d_n));
+            Tout.n = na;
+            if (na) {
+                HIPC(c, hipMemcpyAsync(Tout.xy.p, acc, (size_t)na * 8, hipMemcpyDeviceToDevice, c->stream));
+                hipLaunchKernelGGL(k_stamp_discs, dim3((unsigned)std::min(na, 4096)), dim3(256), 0, c->stream, acc, na, rad_taps, forb, H, W);
+            }
+        }
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}

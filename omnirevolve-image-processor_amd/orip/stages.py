@@ -1,0 +1,224 @@
+"""In-process stage functions with the reference's per-stage inputs / outputs:
+
+    extract_colors(bgr, cfg)            -> {name: mask u8[H,W]}, palette            (02_color_extract.py main)
+    detect_edges(masks, cfg)            -> {name: edges u8[H,W]}                   (03_edge_detect.py process_color)
+    find_contours(edges, cfg)           -> {name: [int32 (N,1,2)]}                 (04_find_contours.py vectorize_layer)
+    scale_vectors / sort_contours / dedup_layer / dedup_cross / plot_order         (05, 07, 08, 10, 12)
+    run_path(bgr, cfg)                  -> ops per layer, everything resident on the GPU between stages
+
+Every function drives liborip.so through orip.device.Device; arrays cross the host boundary only where the
+reference's stage API puts a file.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _l
+from .config import Config, canvas_size_px, scale_factors
+from .device import Device
+
+_dev: Device | None = None
+
+
+def device(device_id: int = 0) -> Device:
+    global _dev
+    if _dev is None:
+        _dev = Device(device_id)
+    return _dev
+
+
+# ---------------------------------------------------------------- naming rules of the reference
+def darkness_rank02(name: str) -> int:  # 02:17-23
+    s = name.lower()
+    if "dark" in s: return 0
+    if "mid" in s: return 1
+    if "skin" in s: return 2
+    if "light" in s: return 3
+    return 2
+
+
+def darkness_rank10(name: str) -> int:  # 10:206-208
+    order = ["layer_dark", "layer_mid", "layer_skin", "layer_light"]
+    return order.index(name) if name in order else 999
+
+
+def color_index12(name: str) -> int:  # 12:210-219
+    if "dark" in name: return 3
+    if "skin" in name: return 0
+    if "mid" in name: return 1
+    if "light" in name: return 2
+    return 0
+
+
+def cluster_names(cfg: Config) -> List[str]:
+    """i-th darkest cluster <-> i-th name of sorted(names, key=_darkness_rank) (02:130-133); device layer l = cluster l."""
+    return sorted(list(cfg.color_names), key=darkness_rank02)
+
+
+def subsample_indices(n: int, limit: int = 200_000):  # 02:39-44
+    if n > limit:
+        return np.random.default_rng(42).choice(n, size=limit, replace=False)
+    return None
+
+
+def ensure_odd(n: int) -> int:  # 03:9-11
+    n = max(3, int(n))
+    return n if n % 2 == 1 else n + 1
+
+
+# ---------------------------------------------------------------- derived parameter blocks
+def params08(cfg: Config) -> _l.Params08:  # 08:484-509
+    pen_diam = float(cfg.pen_width_px); pen_radius = float(cfg.pen_radius_px)
+    W, H = canvas_size_px(cfg)
+    col_rad = float(cfg.collision_radius_intra_px)
+    post_brush = 16
+    return _l.Params08(tap_diam=pen_diam, tap_max_dim=float(cfg.tap_max_dim), min_keep=max(10.0, pen_radius * 0.4),
+                       tap_max_per=float(cfg.tap_max_perimeter), tap_max_v=50, sample_step=float(cfg.dedup_sample_step),
+                       tail_len_px=float(cfg.ignore_tail_points_intra), col_rad=col_rad, grid_stride=float(cfg.hash_stride_px),
+                       max_jump=float(cfg.max_join_jump_px), post_on=1, post_brush=post_brush, post_step=6.0,
+                       post_eps=max(1.0, 0.08 * post_brush), post_minlen=max(2 * post_brush, 12), W=W, H=H,
+                       brush_forbid=max(1, int(round(2.0 * col_rad))))
+
+
+def params10(cfg: Config) -> _l.Params10:  # 10:217-229
+    pen_diam = float(cfg.pen_width_px); W, H = canvas_size_px(cfg)
+    return _l.Params10(tap_diam=pen_diam, min_keep=max(10.0, (pen_diam / 2.0) * 0.4), tap_max_per=2.5 * pen_diam, tap_max_v=50,
+                       max_jump=float(cfg.max_join_jump_px), D_lines=pen_diam * 2.0, D_taps=pen_diam * 2.0, step_px=1.0, W=W, H=H)
+
+
+def r_insert12(cfg: Config) -> float:  # 12:197
+    return float(max(80.0, cfg.pen_width_px))
+
+
+# ---------------------------------------------------------------- stage functions (host arrays in / out)
+def extract_colors(bgr: np.ndarray, cfg: Config, centers: np.ndarray | None = None, dev: Device | None = None):
+    """02 main(), k-means mode.  Returns (masks {name: u8[H,W]}, info) with info = centres (dark->light), counts, labels."""
+    d = dev or device()
+    names = list(cfg.color_names)
+    K = max(2, len(names))
+    d.set_image(bgr)
+    if centers is None:
+        idx = subsample_indices(d.H * d.W)
+        centers, _ = d.kmeans_fit(idx, K)
+    cs, counts = d.extract_layers(np.asarray(centers, np.float32))
+    masks = {n: d.get_mask(l) for l, n in enumerate(cluster_names(cfg)[:K])}
+    return masks, {"centers_lab": cs, "counts": counts, "centers_fit": np.asarray(centers, np.float32)}
+
+
+def detect_edges(masks: Dict[str, np.ndarray], cfg: Config, dev: Device | None = None) -> Dict[str, np.ndarray]:
+    d = dev or device()
+    names = list(masks.keys())
+    d.set_masks(np.stack([masks[n] for n in names]))
+    _detect_edges_resident(d, cfg)
+    return {n: d.get_edges(l) for l, n in enumerate(names)}
+
+
+def _detect_edges_resident(d: Device, cfg: Config):
+    d.detect_edges(max(1, int(cfg.edge_morph_kernel)), int(cfg.edge_morph_open_iters), int(cfg.edge_morph_close_iters),
+                   ensure_odd(cfg.edge_kernel_size), int(math.floor(cfg.edge_low_threshold)), int(math.floor(cfg.edge_high_threshold)))
+
+
+def find_contours(edges: Dict[str, np.ndarray], cfg: Config | None = None, dev: Device | None = None) -> Dict[str, List[np.ndarray]]:
+    d = dev or device()
+    names = list(edges.keys())
+    d.set_edges(np.stack([edges[n] for n in names]))
+    d.find_contours()
+    return {n: d.get_polys(_l.SLOT_CONTOURS, l) for l, n in enumerate(names)}
+
+
+def scale_vectors(contours: Sequence[np.ndarray], w_src: int, h_src: int, cfg: Config, dev: Device | None = None, layer: int = 0):
+    d = dev or device()
+    d.set_polys(_l.SLOT_CONTOURS, layer, contours)
+    sx, sy, dx, dy = scale_factors(cfg, w_src, h_src)
+    d.scale_vectors(layer, sx, sy, dx, dy)
+    return d.get_polys(_l.SLOT_SCALED, layer)
+
+
+def sort_contours(contours: Sequence[np.ndarray], dev: Device | None = None, layer: int = 0):
+    d = dev or device()
+    d.set_polys(_l.SLOT_SCALED, layer, contours)
+    d.sort_contours(layer)
+    return d.get_polys(_l.SLOT_SORTED, layer)
+
+
+def dedup_layer(contours_sorted: Sequence[np.ndarray], cfg: Config, dev: Device | None = None, layer: int = 0):
+    d = dev or device()
+    d.set_polys(_l.SLOT_SORTED, layer, contours_sorted)
+    d.dedup_layer(layer, params08(cfg))
+    return d.get_polys(_l.SLOT_LINES_INTRA, layer), d.get_taps(_l.TAPS_INTRA, layer)
+
+
+def dedup_cross(intra: Dict[str, Tuple[Sequence[np.ndarray], Sequence[Tuple[int, int]]]], cfg: Config, dev: Device | None = None):
+    d = dev or device()
+    names = list(cfg.color_names)
+    for l, n in enumerate(names):
+        lines, taps = intra.get(n, ([], []))
+        d.set_polys(_l.SLOT_LINES_INTRA, l, lines)
+        d.set_taps(_l.TAPS_INTRA, l, taps)
+    order = sorted(range(len(names)), key=lambda l: darkness_rank10(names[l]))
+    d.dedup_cross(order, params10(cfg))
+    return {n: (d.get_polys(_l.SLOT_LINES_CROSS, l), d.get_taps(_l.TAPS_CROSS, l)) for l, n in enumerate(names)}
+
+
+def ops_from_device(d: Device, layer: int, R: float) -> List[dict]:
+    raw = d.plot_order(layer, R)
+    lines = d.get_polys(_l.SLOT_LINES_CROSS, layer) if len(raw) else []
+    ops = []
+    for t, idx, flip, x, y in raw:
+        if t == 0:
+            p = np.asarray(lines[idx]).reshape(-1, 2).astype(np.float32)
+            ops.append({"type": "line", "points": p[::-1].copy() if flip else p})
+        else:
+            ops.append({"type": "tap", "x": int(x), "y": int(y)})
+    return ops
+
+
+def plot_order(lines: Sequence[np.ndarray], taps: Sequence[Tuple[int, int]], cfg: Config, dev: Device | None = None, layer: int = 0) -> List[dict]:
+    d = dev or device()
+    d.set_polys(_l.SLOT_LINES_CROSS, layer, lines)
+    d.set_taps(_l.TAPS_CROSS, layer, taps)
+    return ops_from_device(d, layer, r_insert12(cfg))
+
+
+# ---------------------------------------------------------------- the resident end-to-end path
+def run_path(bgr: np.ndarray, cfg: Config, dev: Device | None = None, centers: np.ndarray | None = None, upto: int = 12,
+             fetch_ops: bool = True):
+    """Stages 02 -> `upto` with every intermediate artefact resident on the GPU.  Device layer l carries the l-th darkest
+    cluster, i.e. the name cluster_names(cfg)[l].  Returns {name: ops} (or None when upto < 12 / fetch_ops False)."""
+    d = dev or device()
+    names = list(cfg.color_names)
+    K = max(2, len(names))
+    lnames = cluster_names(cfg)[:K]
+    H, W = bgr.shape[:2]
+    d.set_image(bgr)
+    if centers is None:
+        centers, _ = d.kmeans_fit(subsample_indices(H * W), K)
+    d.extract_layers(np.asarray(centers, np.float32), want_counts=False)
+    if upto < 3: return None
+    _detect_edges_resident(d, cfg)
+    if upto < 4: return None
+    d.find_contours()
+    if upto < 5: return None
+    sx, sy, dx, dy = scale_factors(cfg, W, H)
+    for l in range(K):
+        d.scale_vectors(l, sx, sy, dx, dy)
+    if upto < 7: return None
+    for l in range(K):
+        d.sort_contours(l)
+    if upto < 8: return None
+    p8 = params08(cfg)
+    for l in range(K):
+        d.dedup_layer(l, p8)
+    if upto < 10: return None
+    order = sorted(range(K), key=lambda l: (darkness_rank10(lnames[l]), names.index(lnames[l])))
+    d.dedup_cross(order, params10(cfg))
+    if upto < 12: return None
+    R = r_insert12(cfg)
+    if not fetch_ops:
+        for l in range(K):
+            d.plot_order(l, R)
+        return None
+    return {lnames[l]: ops_from_device(d, l, R) for l in range(K)}

@@ -1,0 +1,120 @@
+"""GPU parity tests (through the C ABI) for the vector half of the path: stages 05, 07, 08, 10, 12.
+Inputs and expected outputs come from the reference's own stage drivers (golden_e2e_*.npz) and from the oracle
+on seeded random polylines.  Bit-exact: integer point lists, tap lists, op order."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from util import load, unflat, same_polys
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from orip.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def _cfgobj(d):
+    from orip.config import Config
+    c = Config()
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+def _taps(a):
+    return [(int(x), int(y)) for x, y in a]
+
+
+def _rand_polys(rng, n, lo=2, hi=40, span=8000, step=15, closed_p=0.3):
+    out = []
+    for _ in range(n):
+        m = int(rng.integers(lo, hi))
+        p = (np.cumsum(rng.integers(-step, step + 1, (m, 2)), axis=0) + rng.integers(200, span, 2)).astype(np.int32)
+        if rng.random() < closed_p and m > 3:
+            p[-1] = p[0]
+        out.append(p.reshape(-1, 1, 2))
+    return out
+
+
+@pytest.fixture(scope="module", params=["a", "b"])
+def G(request):
+    return load(f"golden_e2e_{request.param}.npz")
+
+
+def test_stage05_07_golden(dev, G):
+    from orip import stages as S
+    cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd); H, W = G["img"].shape[:2]
+    for n in cfgd["color_names"]:
+        scaled = S.scale_vectors(unflat(G, f"contours_{n}"), W, H, cfg, dev)
+        assert same_polys(scaled, unflat(G, f"scaled_{n}")), n
+        assert same_polys(S.sort_contours(unflat(G, f"scaled_{n}"), dev), unflat(G, f"sorted_{n}")), n
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_stage07_random_vs_oracle(dev, seed):
+    from orip import stages as S
+    rng = np.random.default_rng(seed)
+    polys = _rand_polys(rng, [1, 37, 1500][seed])
+    assert same_polys(S.sort_contours(polys, dev), O.sort07(polys))
+
+
+def test_stage10_golden(dev, G):
+    from orip import stages as S
+    cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd)
+    intra = {n: (unflat(G, f"lines_intra_{n}"), _taps(G[f"taps_intra_{n}"])) for n in cfgd["color_names"]}
+    out = S.dedup_cross(intra, cfg, dev)
+    for n in cfgd["color_names"]:
+        assert out[n][1] == _taps(G[f"taps_cross_{n}"]), n
+        assert same_polys(out[n][0], unflat(G, f"lines_cross_{n}")), n
+
+
+def test_stage10_random_vs_oracle(dev):
+    from orip import stages as S
+    rng = np.random.default_rng(5)
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=8, color_names=["layer_dark", "layer_mid", "x_extra", "layer_light"])   # canvas 1680x2376
+    cfg = _cfgobj(cfgd)
+    intra = {}
+    for n in cfgd["color_names"]:
+        lines = _rand_polys(rng, 60, lo=2, hi=25, span=1500, step=40, closed_p=0.0)
+        taps = _taps(rng.integers(-30, 1700, (25, 2)))
+        intra[n] = (lines, taps)
+    want = O.stage10(intra, cfgd)
+    got = S.dedup_cross(intra, cfg, dev)
+    for n in cfgd["color_names"]:
+        assert got[n][1] == want[n][1], n
+        assert same_polys(got[n][0], want[n][0]), n
+
+
+def test_stage12_golden(dev, G):
+    from orip import stages as S
+    cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd)
+    for n in cfgd["color_names"]:
+        ops = S.plot_order(unflat(G, f"lines_cross_{n}"), _taps(G[f"taps_cross_{n}"]), cfg, dev)
+        kinds = np.array([0 if o["type"] == "line" else 1 for o in ops], np.int32)
+        assert np.array_equal(kinds, G[f"ops_kinds_{n}"]), n
+        got = [o["points"] if o["type"] == "line" else np.array([[o["x"], o["y"]]]) for o in ops]
+        assert same_polys(got, unflat(G, f"ops_{n}")), n
+
+
+@pytest.mark.parametrize("case", [(0, 7), (9, 0), (300, 120), (1, 1)])
+def test_stage12_random_vs_oracle(dev, case):
+    from orip import stages as S
+    rng = np.random.default_rng(case[0] + case[1])
+    lines = _rand_polys(rng, case[0], lo=2, hi=12, span=3000, step=25, closed_p=0.0)
+    taps = _taps(rng.integers(0, 3000, (case[1], 2)))
+    cfg = _cfgobj(dict(O.DEFAULTS))
+    want = O.stage12(lines, taps, dict(O.DEFAULTS))
+    got = S.plot_order(lines, taps, cfg, dev)
+    assert [o["type"] for o in got] == [o["type"] for o in want]
+    for a, b in zip(got, want):
+        if a["type"] == "line":
+            assert np.array_equal(a["points"], b["points"])
+        else:
+            assert (a["x"], a["y"]) == (b["x"], b["y"])
