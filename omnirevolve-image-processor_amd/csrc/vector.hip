@@ -177,7 +177,3 @@ extern "C" int orip_get_ops(orip_ctx* c, int layer, int32_t* ops5) {
     return 0;
 }
 
-// placeholders until vector08.hip / vector10.hip land
-#ifndef ORIP_HAVE_08
-extern "C" int orip_dedup_layer(orip_ctx* c, int, const orip_params08*) { ORIP_FAIL(c, "not implemented yet"); }
-#endif

@@ -1,0 +1,725 @@
+// csrc/vector08.hip -- stage 08 (08_dedup_layer_basic.py process_layer, 08:484-557) on gfx950.
+//
+// Stage A (greedy virtual draw, 08:117-183) is NOT sequential on the GPU.  In the reference every sample of every
+// polyline is pushed to the tail and later popped (hash add + thick-line stamp) whether or not it was accepted, so the
+// stamp sequence depends only on the resampled geometry and on the processing order (perimeter, descending).  Giving
+// every popped sample its global sequence number g, sample (r, j) sees exactly the stamps with g < base[r] + npop(r, j).
+// The canvas therefore stores, per pixel, the SMALLEST sequence number of any capsule covering it (atomicMin), and all
+// samples of all polylines of the layer are tested in parallel.  Self-collision (_PointHash, 08:68-99) is a sorted
+// (polyline, cell) bucket list scanned in pop order.
+// Stage B (_post_skeleton_merge, 08:376-469) runs all clusters at once on one padded canvas: clusters are >= 76 px apart
+// in one axis, so per-ROI rasterise / thin / label equals whole-canvas rasterise / thin / label (DESIGN.md "stage 08-B").
+#include "vec_common.h"
+#define PAD8 64
+
+int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst);
+
+namespace {
+
+// ================================================================= A0 / A7: _split_small_and_taps (08:198-216)
+__global__ __launch_bounds__(128) void k_split_small08(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params08 P,
+                                                        unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy, GatherDesc* __restrict__ kd) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_polys) return;
+    if (i == n_polys) { is_tap[i] = 0; is_keep[i] = 0; return; }
+    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
+    unsigned tap = 0, keep = 0;
+    GatherDesc g; g.begin = off[i]; g.len = n; g.rev = 0; g.pad = 0;
+    if (n >= 2) {
+        int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
+        for (int64_t k = 1; k < n; k++) { x0 = min(x0, p[2 * k]); x1 = max(x1, p[2 * k]); y0 = min(y0, p[2 * k + 1]); y1 = max(y1, p[2 * k + 1]); }
+        double d = (double)max(x1 - x0, y1 - y0);
+        if (d <= P.tap_diam && d <= P.tap_max_dim && n <= (int64_t)P.tap_max_v) {      // the vertex test is evaluated last in the reference but decides alone
+            double per = (double)vs::pairwise_seglen_sum<0>(p, n);
+            if (per <= P.tap_max_per) {
+                float cx, cy, r; vs::min_enclosing_circle(p, n, cx, cy, r);
+                tap = 1; tap_xy[i] = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy));
+            }
+        }
+        if (!tap && !(d < P.min_keep)) {
+            keep = 1;
+            if (p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) g.len = n - 1;      // _ensure_open
+        }
+    }
+    is_tap[i] = tap; is_keep[i] = keep; kd[i] = g;
+}
+__global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict__ flag, const unsigned* __restrict__ scan, int64_t n, const GatherDesc* __restrict__ in,
+                                                       GatherDesc* __restrict__ out, const int2* __restrict__ tap_xy, int2* __restrict__ taps_out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    if (out) out[scan[i]] = in[i];
+    if (taps_out) taps_out[scan[i]] = tap_xy[i];
+}
+
+// ================================================================= A2: resample (08:53-64)
+struct RsInfo { int64_t n_eff; double total; unsigned m; unsigned pass; };
+// sequential float32 cumsum per polyline (np.cumsum), one lane per polyline
+__global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
+                                                 float* __restrict__ cum, RsInfo* __restrict__ info) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_polys) return;
+    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
+    float* s = cum + off[i];
+    RsInfo r; r.n_eff = n; r.total = 0; r.m = 0; r.pass = 0;
+    if (n >= 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;         // _ensure_open inside _virtual_draw (08:127)
+    r.n_eff = n;
+    if (n >= 2) {
+        if (n > 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;    // _is_closed inside _resample_arclen (08:56)
+        r.n_eff = n;
+        float acc = 0.f; s[0] = 0.f;
+        for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32(p, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
+        r.total = (double)acc;
+        if (r.total <= step) { r.pass = 1; r.m = (unsigned)n; }
+        else r.m = (unsigned)ceil(r.total / step);
+        if (r.m < 2) r.m = 0;                                                         // len(S) < 2 -> nothing is drawn or stamped (08:130)
+    }
+    info[i] = r;
+}
+__global__ __launch_bounds__(256) void k_rank_counts(const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t n, unsigned* __restrict__ mr) {
+    int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) mr[r] = info[ord[r]].m;
+    if (r == n) mr[r] = 0;
+}
+__device__ __forceinline__ int64_t ub_u32v(const unsigned* a, int64_t n, unsigned v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+struct SampleArrs { double* sx; double* sy; int* xi; int* yi; unsigned* rank; uint8_t* inc; };
+__global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, const float* __restrict__ cum,
+                                                  const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
+                                                  unsigned MS, double step, int W, int H, SampleArrs A) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    int64_t r = ub_u32v(sbase, n_rank, g) - 1;
+    while (info[ord[r]].m == 0) r--;
+    unsigned i = ord[r]; unsigned j = g - sbase[r];
+    const int32_t* p = pts + 2 * off[i]; const float* s = cum + off[i];
+    RsInfo ri = info[i];
+    double x, y;
+    if (ri.pass) { x = (double)(float)p[2 * j]; y = (double)(float)p[2 * j + 1]; }
+    else {
+        float t0 = 0.0f, t1 = (float)(0.0 + step), delta = __fsub_rn(t1, t0);
+        float tf = j == 0 ? t0 : (j == 1 ? t1 : __fadd_rn(t0, __fmul_rn((float)j, delta)));
+        double t = (double)tf;
+        // searchsorted(s, t, 'right') - 1 on s[0..n_eff), clipped to [0, n_eff-2]
+        int64_t lo = 0, hi = ri.n_eff;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((double)s[mid] <= t) lo = mid + 1; else hi = mid; }
+        int64_t k = lo - 1; if (k < 0) k = 0; if (k > ri.n_eff - 2) k = ri.n_eff - 2;
+        double sk = (double)s[k], sk1 = (double)s[k + 1];
+        double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
+        double a = __dsub_rn(1.0, u);
+        x = __dadd_rn(__dmul_rn((double)(float)p[2 * k], a), __dmul_rn((double)(float)p[2 * k + 2], u));
+        y = __dadd_rn(__dmul_rn((double)(float)p[2 * k + 1], a), __dmul_rn((double)(float)p[2 * k + 3], u));
+    }
+    long long xi = vs::round_half_even(x), yi = vs::round_half_even(y);
+    A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
+    bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
+    A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
+}
+
+// ================================================================= A3: tail simulation (08:139-155), one lane per polyline
+__global__ __launch_bounds__(128) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A,
+                                                   unsigned* __restrict__ npop, int* __restrict__ capprev) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rank) return;
+    unsigned b = sbase[r], e = sbase[r + 1];
+    if (e <= b) return;
+    const double* X = A.sx + b; const double* Y = A.sy + b; const uint8_t* IN = A.inc + b;
+    unsigned m = e - b, head = 0; double tail_len = 0.0;
+    int last_in = -1;
+    auto pop_stamp = [&](unsigned j) { if (IN[j]) { capprev[b + j] = last_in; last_in = (int)j; } else capprev[b + j] = -2; };
+    for (unsigned j = 0; j < m; j++) {
+        if (j > head) tail_len += vs::norm2_f64(X[j] - X[j - 1], Y[j] - Y[j - 1]);          // tail = samples [head, j)
+        // while tail and tail_len > limit: pop
+        while (head <= j && tail_len > tail_len_px) {
+            unsigned o = head; head++;
+            if (head <= j) tail_len -= vs::norm2_f64(X[head] - X[o], Y[head] - Y[o]); else tail_len = 0.0;
+            pop_stamp(o);
+        }
+        npop[b + j] = head;
+    }
+    for (unsigned o = head; o < m; o++) pop_stamp(o);     // final flush (08:173-180)
+}
+
+// ================================================================= A4: capsule de-duplication + min-sequence stamping
+__device__ __forceinline__ unsigned long long cap_key(int x0, int y0, int x1, int y1) {
+    unsigned long long a = ((unsigned long long)(unsigned)x0 << 14) | (unsigned)y0, b = ((unsigned long long)(unsigned)x1 << 14) | (unsigned)y1;
+    if (b < a) { unsigned long long t = a; a = b; b = t; }
+    return ((a << 28) | b) + 1ULL;     // 0 is the empty marker
+}
+__device__ __forceinline__ unsigned long long hash64(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+__global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigned* __restrict__ sbase, const int* __restrict__ capprev, unsigned MS,
+                                                      unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tvals, unsigned long long tmask) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    int cp = capprev[g];
+    if (cp < 0) return;
+    unsigned b = sbase[A.rank[g]];
+    unsigned long long key = cap_key(A.xi[b + cp], A.yi[b + cp], A.xi[g], A.yi[g]);
+    unsigned long long h = hash64(key) & tmask;
+    while (true) {
+        unsigned long long cur = tkeys[h];
+        if (cur == 0) { unsigned long long old = atomicCAS(&tkeys[h], 0ULL, key); if (old == 0 || old == key) cur = key; else cur = old; }
+        if (cur == key) { atomicMin(&tvals[h], g); return; }
+        h = (h + 1) & tmask;
+    }
+}
+__global__ __launch_bounds__(256) void k_caps_stamp(const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tvals, unsigned long long tsize,
+                                                     int rad, unsigned* __restrict__ firstseq, int W, int H) {
+    const int lane = threadIdx.x & 63;
+    const long long r2 = (long long)rad * rad;
+    unsigned long long wave = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * 256) >> 6;
+    for (unsigned long long s0 = wave * 64; s0 < tsize; s0 += nwaves * 64) {
+        unsigned long long k = (s0 + lane < tsize) ? tkeys[s0 + lane] : 0ULL;
+        unsigned v = k ? tvals[s0 + lane] : 0u;
+        unsigned long long occ = __ballot(k != 0);
+        while (occ) {
+            int src = __ffsll((long long)occ) - 1; occ &= occ - 1;
+            unsigned long long kk = __shfl(k, src, 64) - 1ULL; unsigned seq = __shfl(v, src, 64);
+            unsigned long long a = kk >> 28, b = kk & ((1ULL << 28) - 1);
+            int x0 = (int)(a >> 14), y0 = (int)(a & 16383), x1 = (int)(b >> 14), y1 = (int)(b & 16383);
+            int bx0 = max(0, min(x0, x1) - rad), bx1 = min(W - 1, max(x0, x1) + rad), by0 = max(0, min(y0, y1) - rad), by1 = min(H - 1, max(y0, y1) + rad);
+            int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+            for (int i = lane; i < bw * bh; i += 64) {
+                int x = bx0 + i % bw, y = by0 + i / bw;
+                if (vs::in_capsule(x, y, x0, y0, x1, y1, r2)) atomicMin(&firstseq[(size_t)y * W + x], seq);
+            }
+        }
+    }
+}
+
+// ================================================================= A5: _PointHash.near (08:85-93)
+__device__ __forceinline__ unsigned long long cell_key(unsigned r, long long cx, long long cy) {
+    return ((unsigned long long)r << 32) | ((unsigned long long)((cx + 32768) & 0xffff) << 16) | (unsigned long long)((cy + 32768) & 0xffff);
+}
+__global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, double inv, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    long long cx = (long long)floor(__dmul_rn(A.sx[g], inv)), cy = (long long)floor(__dmul_rn(A.sy[g], inv));
+    keys[g] = cell_key(A.rank[g], cx, cy); vals[g] = g;
+}
+__global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, unsigned MS, double inv, double R2,
+                                                 const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals, const unsigned* __restrict__ firstseq,
+                                                 int W, int2* __restrict__ spt, uint8_t* __restrict__ sflag) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    unsigned r = A.rank[g], b = sbase[r], j = g - b;
+    double x = A.sx[g], y = A.sy[g];
+    bool ok = A.inc[g] != 0;
+    unsigned limit = b + npop[g];        // own samples with global index < limit have been popped (hashed + stamped)
+    if (ok && firstseq[(size_t)A.yi[g] * W + A.xi[g]] < limit) ok = false;
+    if (ok && npop[g] > 0) {
+        long long cx = (long long)floor(__dmul_rn(x, inv)), cy = (long long)floor(__dmul_rn(y, inv));
+        for (int dx = -1; dx <= 1 && ok; dx++)
+            for (int dy = -1; dy <= 1 && ok; dy++) {
+                unsigned long long key = cell_key(r, cx + dx, cy + dy);
+                long long lo = 0, hi = MS;
+                while (lo < hi) { long long mid = (lo + hi) >> 1; if (skeys[mid] < key) lo = mid + 1; else hi = mid; }
+                for (long long q = lo; q < (long long)MS && skeys[q] == key; q++) {
+                    unsigned g2 = svals[q];
+                    if (g2 >= limit) break;                     // buckets are in pop order
+                    double ddx = __dsub_rn(A.sx[g2], x), ddy = __dsub_rn(A.sy[g2], y);
+                    if (__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)) <= R2) { ok = false; break; }
+                }
+            }
+    }
+    spt[g] = make_int2((int)x, (int)y);
+    sflag[g] = (ok ? 1 : 0) | (j == 0 ? 2 : 0);
+}
+
+// ================================================================= B: _post_skeleton_merge
+__device__ __forceinline__ int ufind(const int* L, int a) { int p = L[a]; while (p != a) { a = p; p = L[a]; } return a; }
+__device__ __forceinline__ void uunite(int* L, int a, int b) {
+    bool done;
+    do {
+        a = ufind(L, a); b = ufind(L, b);
+        if (a < b) { int old = atomicMin(&L[b], a); done = (old == b); b = old; }
+        else if (b < a) { int old = atomicMin(&L[a], b); done = (old == a); a = old; }
+        else done = true;
+    } while (!done);
+}
+__global__ __launch_bounds__(256) void k_iota(int* a, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n) a[i] = i; }
+__global__ __launch_bounds__(256) void k_bbox_pairs(const PolyFeat* __restrict__ f, int n, int exp, int* __restrict__ par) {
+    // bboxes expanded by exp on each side overlap  <=>  not separated (08:41-42)
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        int ax0 = f[i].x0 - exp, ay0 = f[i].y0 - exp, ax1 = f[i].x1 + exp, ay1 = f[i].y1 + exp;
+        for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+            int bx0 = f[j].x0 - exp, by0 = f[j].y0 - exp, bx1 = f[j].x1 + exp, by1 = f[j].y1 + exp;
+            if (!(ax1 < bx0 || bx1 < ax0 || ay1 < by0 || by1 < ay0)) uunite(par, i, j);
+        }
+    }
+}
+struct GroupInfo { int x0, y0, x1, y1; unsigned long long longest; unsigned long long near0, near1; int rank; int a0x, a0y, a1x, a1y; };
+__global__ __launch_bounds__(256) void k_group_init(GroupInfo* g, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+    GroupInfo q; q.x0 = q.y0 = 0x7fffffff; q.x1 = q.y1 = -0x7fffffff; q.longest = ~0ULL; q.near0 = q.near1 = ~0ULL; q.rank = -1; q.a0x = q.a0y = q.a1x = q.a1y = 0;
+    g[i] = q;
+}
+__global__ __launch_bounds__(256) void k_group_accum(const PolyFeat* __restrict__ f, int n, int exp, int* __restrict__ par, GroupInfo* __restrict__ g, unsigned* __restrict__ is_root) {
+    int i = blockIdx.x * 256 + threadIdx.x; if (i > n) return;
+    if (i == n) { is_root[i] = 0; return; }
+    int r = ufind(par, i); par[i] = r;
+    is_root[i] = (r == i) ? 1u : 0u;
+    atomicMin(&g[r].x0, f[i].x0 - exp); atomicMin(&g[r].y0, f[i].y0 - exp); atomicMax(&g[r].x1, f[i].x1 + exp); atomicMax(&g[r].y1, f[i].y1 + exp);
+    unsigned long long key = ((unsigned long long)(~__float_as_uint(f[i].per)) << 32) | (unsigned)i;     // longest, first index on ties (08:391)
+    atomicMin(&g[r].longest, key);
+}
+__global__ __launch_bounds__(256) void k_group_finish(const PolyFeat* __restrict__ f, int n, const unsigned* __restrict__ is_root, const unsigned* __restrict__ root_scan, GroupInfo* __restrict__ g) {
+    int i = blockIdx.x * 256 + threadIdx.x; if (i >= n || !is_root[i]) return;
+    g[i].rank = (int)root_scan[i];
+    int l = (int)(g[i].longest & 0xffffffffu);
+    g[i].a0x = f[l].sx; g[i].a0y = f[l].sy; g[i].a1x = f[l].ex; g[i].a1y = f[l].ey;
+}
+// raster: gid[pixel] = group root + 1 for every pixel within r of a segment of a line of the group; one wave per segment
+__global__ __launch_bounds__(256) void k_stamp_groups(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int64_t n_pts, const int* __restrict__ par,
+                                                       int rad, unsigned* __restrict__ gid, int Wp, int Hp) {
+    const int lane = threadIdx.x & 63; const long long r2 = (long long)rad * rad;
+    long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long long)gridDim.x * 256) >> 6;
+    for (long long i = wave; i + 1 < n_pts; i += nw) {
+        // polyline of point i: last off <= i
+        long long lo = 0, hi = n_polys;
+        while (lo < hi) { long long mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+        if (i + 1 >= off[lo + 1]) continue;                 // i is the last point of its polyline
+        unsigned val = (unsigned)par[lo] + 1u;
+        int x0 = pts[2 * i] + PAD8, y0 = pts[2 * i + 1] + PAD8, x1 = pts[2 * i + 2] + PAD8, y1 = pts[2 * i + 3] + PAD8;
+        int bx0 = max(0, min(x0, x1) - rad), bx1 = min(Wp - 1, max(x0, x1) + rad), by0 = max(0, min(y0, y1) - rad), by1 = min(Hp - 1, max(y0, y1) + rad);
+        int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+        if (bw <= 0 || bh <= 0) continue;
+        for (int q = lane; q < bw * bh; q += 64) {
+            int x = bx0 + q % bw, y = by0 + q / bw;
+            if (vs::in_capsule(x, y, x0, y0, x1, y1, r2)) gid[(size_t)y * Wp + x] = val;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_gid_to_mask(const unsigned* __restrict__ gid, u8* __restrict__ m, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i < n) m[i] = gid[i] ? 255 : 0;
+}
+// standard-orientation Zhang-Suen sub-iteration (08:349-366)
+__global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __restrict__ d, int H, int W, int sub, int* __restrict__ changed) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    u8 v = s[o];
+    if (v) {
+        auto g = [&](int dy, int dx) -> int { int yy = y + dy, xx = x + dx; return (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) ? 1 : 0; };
+        int P2 = g(-1, 0), P3 = g(-1, 1), P4 = g(0, 1), P5 = g(1, 1), P6 = g(1, 0), P7 = g(1, -1), P8 = g(0, -1), P9 = g(-1, -1);
+        int Bn = P2 + P3 + P4 + P5 + P6 + P7 + P8 + P9;
+        int A = (!P2 && P3) + (!P3 && P4) + (!P4 && P5) + (!P5 && P6) + (!P6 && P7) + (!P7 && P8) + (!P8 && P9) + (!P9 && P2);
+        bool cnd = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0) : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
+        if (A == 1 && Bn >= 2 && Bn <= 6 && cnd) { v = 0; *changed = 1; }
+    }
+    d[o] = v ? 255 : 0;
+}
+// plain (linear id) union-find CCL on the padded raster
+__global__ __launch_bounds__(256) void k_ccl2_init(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    int id = y * W + x; L[id] = s[id] ? id : -1;
+}
+__global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    int id = y * W + x;
+    if (!s[id]) return;
+    if (x > 0 && s[id - 1]) uunite(L, id, id - 1);
+    if (y > 0) {
+        if (x > 0 && s[id - W - 1]) uunite(L, id, id - W - 1);
+        if (s[id - W]) uunite(L, id, id - W);
+        if (x + 1 < W && s[id - W + 1]) uunite(L, id, id - W + 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_ccl2_flatten(int* __restrict__ L, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n && L[i] >= 0) L[i] = ufind(L, i); }
+// ordered compaction of skeleton pixels (count / write), 1024 px per block
+__global__ __launch_bounds__(256) void k_sk_count(const u8* __restrict__ s, int64_t n, unsigned* __restrict__ counts) {
+    __shared__ unsigned ws[4];
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; unsigned c = 0;
+    for (int j = 0; j < 4; j++) if (i + j < n && s[i + j]) c++;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void k_sk_write(const u8* __restrict__ s, const int* __restrict__ L, int64_t n, const unsigned* __restrict__ boff, unsigned* __restrict__ keys, unsigned* __restrict__ lin) {
+    __shared__ unsigned ws[4];
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; unsigned f[4], c = 0;
+    for (int j = 0; j < 4; j++) { f[j] = (i + j < n && s[i + j]) ? 1u : 0u; c += f[j]; }
+    unsigned inc = c; const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned base = boff[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += ws[w];
+    unsigned pos = base + inc - c;
+    for (int j = 0; j < 4; j++) if (f[j]) { keys[pos] = (unsigned)L[i + j]; lin[pos] = (unsigned)(i + j); pos++; }
+}
+__global__ __launch_bounds__(256) void k_heads2(const unsigned* __restrict__ keys, int64_t m, unsigned* __restrict__ head) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i > m) return;
+    head[i] = (i < m && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_comp_starts2(const unsigned* __restrict__ head, const unsigned* __restrict__ hs, int64_t m, unsigned* __restrict__ cs, unsigned nc) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) cs[nc] = (unsigned)m;
+    if (i < m && head[i]) cs[hs[i]] = (unsigned)i;
+}
+// anchors: nearest skeleton pixel of the group to a0 / a1 (first in raster order on ties, 08:428-432)
+__global__ __launch_bounds__(256) void k_nearest_anchor(const unsigned* __restrict__ lin, int64_t m, const unsigned* __restrict__ gid, int Wp, GroupInfo* __restrict__ g) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i >= m) return;
+    unsigned p = lin[i]; int x = (int)(p % Wp) - PAD8, y = (int)(p / Wp) - PAD8;
+    GroupInfo* G = g + (gid[p] - 1);
+    long long d0 = (long long)(y - G->a0y) * (y - G->a0y) + (long long)(x - G->a0x) * (x - G->a0x);
+    long long d1 = (long long)(y - G->a1y) * (y - G->a1y) + (long long)(x - G->a1x) * (x - G->a1x);
+    atomicMin(&G->near0, ((unsigned long long)d0 << 27) | p);
+    atomicMin(&G->near1, ((unsigned long long)d1 << 27) | p);
+}
+// per component: sort key (group rank, ROI-relative block-raster key of its first block)
+__global__ __launch_bounds__(128) void k_comp_keys(const unsigned* __restrict__ cs, unsigned nc, const unsigned* __restrict__ lin, const unsigned* __restrict__ gid, int Wp,
+                                                    const GroupInfo* __restrict__ g, unsigned long long* __restrict__ ckey, unsigned* __restrict__ cidx) {
+    unsigned c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= nc) return;
+    unsigned b = cs[c], e = cs[c + 1];
+    const GroupInfo* G = g + (gid[lin[b]] - 1);
+    int w = max(1, G->x1 - G->x0); int wb = (w + 1) >> 1;
+    unsigned best = 0xffffffffu;
+    for (unsigned q = b; q < e; q++) {
+        unsigned p = lin[q]; int x = (int)(p % Wp) - PAD8 - G->x0, y = (int)(p / Wp) - PAD8 - G->y0;
+        unsigned k = (unsigned)((y >> 1) * wb + (x >> 1));
+        best = min(best, k);
+    }
+    ckey[c] = ((unsigned long long)(unsigned)G->rank << 32) | best; cidx[c] = c;
+}
+
+__device__ const int OFY[8] = {-1, -1, -1, 0, 1, 1, 1, 0};     // _OFFS (dy,dx), 08:252
+__device__ const int OFX[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+
+struct BfsArrs { const u8* sk; unsigned* seen; int* prev; int* queue; int Wp, Hp; };
+// BFS from src; returns the last dequeued pixel; stops early at goal (goal < 0: full sweep).  stamp identifies this run.
+__device__ int bfs_run(const BfsArrs& B, int* que, int src, int goal, unsigned stamp) {
+    int head = 0, tail = 0; que[tail++] = src; B.seen[src] = stamp; B.prev[src] = -1;
+    int last = src;
+    while (head < tail) {
+        int cpx = que[head++]; last = cpx;
+        if (cpx == goal) break;
+        int y = cpx / B.Wp, x = cpx % B.Wp;
+        for (int k = 0; k < 8; k++) {
+            int ny = y + OFY[k], nx = x + OFX[k];
+            if (ny < 0 || ny >= B.Hp || nx < 0 || nx >= B.Wp) continue;
+            int j = ny * B.Wp + nx;
+            if (!B.sk[j] || B.seen[j] == stamp) continue;
+            B.seen[j] = stamp; B.prev[j] = cpx; que[tail++] = j;
+        }
+    }
+    return last;
+}
+// _component_best_path (08:295-317) + resample(6) + RDP (08:444-463); one lane per component, in output order
+__global__ __launch_bounds__(64) void k_comp_paths(const unsigned* __restrict__ corder, unsigned nc, const unsigned* __restrict__ cs, const unsigned* __restrict__ keys,
+                                                    const unsigned* __restrict__ lin, const unsigned* __restrict__ gid, const GroupInfo* __restrict__ g, BfsArrs B,
+                                                    int min_len, double step, float eps, float2* __restrict__ fbuf, int2* __restrict__ stack, uint8_t* __restrict__ keepb,
+                                                    int2* __restrict__ outpts, unsigned* __restrict__ outcnt) {
+    unsigned oi = blockIdx.x * 64 + threadIdx.x; if (oi >= nc) return;
+    unsigned c = corder[oi];
+    unsigned b = cs[c], e = cs[c + 1]; int size = (int)(e - b);
+    int root = (int)keys[b];
+    const GroupInfo* G = g + (gid[lin[b]] - 1);
+    int* que = B.queue + b; int* path = B.queue + b;    // the queue segment is reused for the final path
+    outcnt[oi] = 0;
+    int a0 = (G->near0 == ~0ULL) ? -1 : (int)(G->near0 & ((1ULL << 27) - 1)), a1 = (G->near1 == ~0ULL) ? -1 : (int)(G->near1 & ((1ULL << 27) - 1));
+    // "comp[a0]" : the anchor pixel belongs to this component.  keys[] holds the root of every listed pixel; look the anchor up through prev-free test:
+    auto in_comp = [&](int p) -> bool { if (p < 0) return false; for (unsigned q = b; q < e; q++) if ((int)lin[q] == p) return true; return false; };
+    bool ha = in_comp(a0), hb = in_comp(a1);
+    (void)root;
+    const int need = max(2, min_len);
+    int plen = 0; int pu = -1, pv = -1;
+    unsigned stamp = 4u * c + 1u;
+    if (ha && hb) {
+        if (a0 == a1) { plen = 1; }
+        else {
+            bfs_run(B, que, a0, a1, stamp);
+            if (B.seen[a1] == stamp) { int cnt = 1, p = a1; while (p != a0) { p = B.prev[p]; cnt++; } plen = cnt; pu = a0; pv = a1; }
+        }
+        if (plen < need) plen = 0;
+    }
+    if (plen == 0) {
+        int seed = (int)lin[b];
+        int u = bfs_run(B, que, seed, -1, stamp + 1);
+        int v = bfs_run(B, que, u, -1, stamp + 2);
+        // path = bfs(u, v): prev[] of the last sweep already holds the tree rooted at u (the sweep from u is exactly _bfs_path's search, cut at v)
+        int cnt = 1, p = v; while (p != u) { p = B.prev[p]; cnt++; }
+        plen = cnt; pu = u; pv = v;
+        if (u == v) plen = 1;
+        if (plen < need) plen = 0;
+    }
+    if (plen < 2) return;
+    // materialise path u -> v (backtrack from v)
+    { int p = pv; for (int k = plen - 1; k >= 0; k--) { path[k] = p; p = B.prev[p]; } }
+    (void)pu; (void)size;
+    // float32 absolute coordinates; float32 cumsum; resample to float64 then back to float32 (08:444-452)
+    float2* P = fbuf + b;
+    float total = 0.f;
+    {
+        float px = (float)(path[0] % B.Wp - PAD8), py = (float)(path[0] / B.Wp - PAD8);
+        for (int k = 1; k < plen; k++) {
+            float qx = (float)(path[k] % B.Wp - PAD8), qy = (float)(path[k] / B.Wp - PAD8);
+            float dx = qx - px, dy = qy - py; float s = sqrtf(dx * dx + dy * dy);
+            total = (k == 1) ? s : total + s;
+            px = qx; py = qy;
+        }
+    }
+    int m;
+    if ((double)total <= step) { m = plen; for (int k = 0; k < plen; k++) P[k] = make_float2((float)(path[k] % B.Wp - PAD8), (float)(path[k] / B.Wp - PAD8)); }
+    else {
+        m = (int)ceil((double)total / step);
+        float t0 = 0.0f, t1 = (float)(0.0 + step), delta = t1 - t0;
+        int k = 0; float sk = 0.f;          // s[k]; advance with the same sequential cumsum
+        float ax = (float)(path[0] % B.Wp - PAD8), ay = (float)(path[0] / B.Wp - PAD8);
+        float bx = (float)(path[1] % B.Wp - PAD8), by = (float)(path[1] / B.Wp - PAD8);
+        float dx0 = bx - ax, dy0 = by - ay; float seg = sqrtf(dx0 * dx0 + dy0 * dy0); float sk1 = seg;   // s[1]
+        for (int i = 0; i < m; i++) {
+            float tf = i == 0 ? t0 : (i == 1 ? t1 : t0 + (float)i * delta);
+            double t = (double)tf;
+            while (k + 2 < plen && (double)sk1 <= t) {       // searchsorted(right)-1, clipped to plen-2
+                k++; sk = sk1; ax = bx; ay = by;
+                bx = (float)(path[k + 1] % B.Wp - PAD8); by = (float)(path[k + 1] / B.Wp - PAD8);
+                float ddx = bx - ax, ddy = by - ay; float sg = sqrtf(ddx * ddx + ddy * ddy);
+                sk1 = sk + sg;
+            }
+            double u = ((t - (double)sk)) / fmax(1e-6, (double)sk1 - (double)sk);
+            double a = 1.0 - u;
+            double X = (double)ax * a + (double)bx * u, Y = (double)ay * a + (double)by * u;
+            P[i] = make_float2((float)X, (float)Y);
+        }
+    }
+    if (m < 2) return;
+    // RDP with an explicit LIFO stack (08:453-462)
+    uint8_t* keep = keepb + b; int2* st = stack + b;
+    for (int i = 0; i < m; i++) keep[i] = 0;
+    keep[0] = keep[m - 1] = 1;
+    int sp = 0; st[sp++] = make_int2(0, m - 1);
+    while (sp > 0) {
+        int2 se = st[--sp]; int s = se.x, en = se.y;
+        if (en <= s + 1) continue;
+        float ax = P[s].x, ay = P[s].y, bx = P[en].x, by = P[en].y;
+        float segx = bx - ax, segy = by - ay, nx = -segy, ny = segx;
+        float q = segx * segx + segy * segy;
+        double seg_len = (double)sqrtf(q) + 1e-12; float seg_len_f = (float)seg_len;
+        float bestd = -1.f; int bi = 0;
+        for (int i = s + 1; i < en; i++) {
+            float dx = P[i].x - ax, dy = P[i].y - ay;
+            float t0 = dx * nx, t1 = dy * ny;
+            float d = fabsf(t0 + t1) / seg_len_f;
+            if (d > bestd) { bestd = d; bi = i; }
+        }
+        if (bestd > eps) { keep[bi] = 1; st[sp++] = make_int2(s, bi); st[sp++] = make_int2(bi, en); }
+    }
+    int2* o = outpts + b; unsigned cnt = 0;
+    for (int i = 0; i < m; i++) if (keep[i]) o[cnt++] = make_int2((int)P[i].x, (int)P[i].y);
+    outcnt[oi] = cnt;
+}
+__global__ __launch_bounds__(256) void k_path_desc(const unsigned* __restrict__ corder, const unsigned* __restrict__ cs, const unsigned* __restrict__ outcnt, const unsigned* __restrict__ flag,
+                                                    const unsigned* __restrict__ scan, unsigned nc, GatherDesc* __restrict__ d) {
+    unsigned oi = blockIdx.x * 256 + threadIdx.x; if (oi >= nc || !flag[oi]) return;
+    GatherDesc g; g.begin = cs[corder[oi]]; g.len = outcnt[oi]; g.rev = 0; g.pad = 0;
+    d[scan[oi]] = g;
+}
+__global__ __launch_bounds__(256) void k_flag_nonzero(const unsigned* __restrict__ v, unsigned n, unsigned* __restrict__ f) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x; if (i < n) f[i] = v[i] >= 2 ? 1u : 0u; if (i == n) f[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_concat_taps(const int2* a, int64_t na, const int2* b, int64_t nb, int2* out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) out[i] = a[i]; else if (i < na + nb) out[i] = b[i - na];
+}
+
+// split_small_and_taps on a DPolys -> kept (opened) + taps appended to tapbuf at tap_base
+int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, DBuf& tapbuf, int64_t tap_base, int64_t* n_taps_out) {
+    kept.n = 0; kept.total = 0; *n_taps_out = 0;
+    HIPC(c, kept.off.ensure(64)); HIPC(c, hipMemsetAsync(kept.off.p, 0, 8, c->stream));
+    int64_t n = src.n;
+    if (n == 0) return 0;
+    HIPC(c, c->vtmp[2].ensure((size_t)(n + 1) * (16 + 8 + 2 * sizeof(GatherDesc)) + 256));
+    unsigned* is_tap = c->vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (n + 1); unsigned* tap_scan = is_keep + (n + 1); unsigned* keep_scan = tap_scan + (n + 1);
+    int2* tap_xy = (int2*)(keep_scan + (n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (n + 1)); GatherDesc* kd2 = kd + (n + 1);
+    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, c->stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, is_tap, is_keep, tap_xy, kd); }
+    ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
+    ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
+    unsigned nt = 0, nk = 0;
+    ORIP_TRY(vread(c, &nt, tap_scan + n)); ORIP_TRY(vread(c, &nk, keep_scan + n));
+    if (nt) {
+        HIPC(c, tapbuf.ensure((size_t)(tap_base + nt) * 8 + 64, c->stream, true));
+        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, is_tap, tap_scan, n, (const GatherDesc*)nullptr, (GatherDesc*)nullptr, tap_xy, tapbuf.as<int2>() + tap_base);
+    }
+    *n_taps_out = nt;
+    if (nk) {
+        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, is_keep, keep_scan, n, kd, kd2, (const int2*)nullptr, (int2*)nullptr);
+        ORIP_TRY(vgather(c, kd2, nk, src.pts.as<int32_t>(), kept));
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_fill_per(const PolyFeat* __restrict__ f, int64_t n, float* __restrict__ k, unsigned* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { k[i] = f[i].per; v[i] = (unsigned)i; }
+}
+
+struct TmpPolys { DPolys p; ~TmpPolys() { p.off.release(); p.pts.release(); } };
+
+}  // namespace
+
+extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm) {
+    if (!prm || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
+    const orip_params08 P = *prm;
+    const int W = P.W, H = P.H;
+    if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
+    if (!(P.sample_step * 2.0 < P.max_jump)) ORIP_FAIL(c, "dedup_sample_step must be < max_join_jump_px / 2 (stage-A segments are assumed jump-free)");
+    DPolys& S = c->polys[ORIP_SLOT_SORTED][layer]; DPolys& OUT = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DTaps& TOUT = c->taps[ORIP_TAPS_INTRA][layer];
+    OUT.n = 0; OUT.total = 0; TOUT.n = 0;
+    HIPC(c, OUT.off.ensure(64)); HIPC(c, hipMemsetAsync(OUT.off.p, 0, 8, c->stream));
+    HIPC(c, TOUT.xy.ensure(64));
+    if (S.n == 0) return 0;
+    TmpPolys kept0, cleaned, lines2, merged;
+    int64_t nt0 = 0, nt2 = 0;
+    // ---- A0
+    ORIP_TRY(split_small(c, S, P, kept0.p, TOUT.xy, 0, &nt0));
+    const int64_t nk = kept0.p.n;
+    if (nk > 0) {
+        if (kept0.p.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
+        // ---- A1: order by perimeter, descending, stable
+        HIPC(c, c->vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
+        PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
+        { ProfScope ps(c, "k_poly_features"); hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, 1, feat); }
+        HIPC(c, c->vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
+        float* kin = c->vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
+        unsigned* mr = ord + nk; unsigned* sbase = mr + (nk + 1); RsInfo* info = (RsInfo*)(sbase + (nk + 1) + 2);   // (6 nk + 4) dwords: 8-byte aligned
+        hipLaunchKernelGGL(k_fill_per, dim3(cdiv(nk, 256)), dim3(256), 0, c->stream, feat, nk, kin, vin);
+        ORIP_TRY((vsort_pairs<float, unsigned>(c, kin, kout, vin, ord, (size_t)nk, 0, 32, true)));
+        // ---- A2: resample
+        HIPC(c, c->vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
+        float* cum = c->vtmp[1].as<float>();
+        const double step = std::max(1.0, P.sample_step);
+        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
+        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, c->stream, info, ord, nk, mr);
+        ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
+        unsigned MS = 0;
+        ORIP_TRY(vread(c, &MS, sbase + nk));
+        if (MS > 0) {
+            if (MS > 0x7ffffff0u) ORIP_FAIL(c, "too many samples");
+            HIPC(c, c->vtmp[3].ensure((size_t)MS * (8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
+            SampleArrs A; A.sx = c->vtmp[3].as<double>(); A.sy = A.sx + MS; A.xi = (int*)(A.sy + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
+            unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
+            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
+            // ---- A3
+            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, sbase, nk, P.tail_len_px, A, npop, capprev); }
+            // ---- A4: de-duplicated capsules -> min-sequence canvas
+            HIPC(c, c->canvas.ensure((size_t)W * H * 4 + 64));
+            unsigned* firstseq = c->canvas.as<unsigned>();
+            HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, c->stream));
+            unsigned long long tsize = 1024; while (tsize < 2ull * MS) tsize <<= 1;
+            HIPC(c, c->vtmp[4].ensure((size_t)tsize * 12 + 64));
+            unsigned long long* tkeys = c->vtmp[4].as<unsigned long long>(); unsigned* tvals = (unsigned*)(tkeys + tsize);
+            HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, c->stream));
+            HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, c->stream));
+            { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1); }
+            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, c->stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
+            // ---- A5: (polyline, cell) buckets in pop order
+            HIPC(c, c->vtmp[5].ensure((size_t)MS * 24 + 64));
+            unsigned long long* ckin = c->vtmp[5].as<unsigned long long>(); unsigned long long* ckout = ckin + MS; unsigned* cvin = (unsigned*)(ckout + MS); unsigned* cvout = cvin + MS;
+            const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
+            hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, MS, inv, ckin, cvin);
+            int rbits = 1; while ((1ll << rbits) < nk + 1) rbits++;
+            { ProfScope ps(c, "sort_cells"); ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cvin, cvout, (size_t)MS, 0, 32 + rbits))); }
+            // ---- A6
+            { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, sbase, npop, MS, inv, P.col_rad * P.col_rad, ckout, cvout, firstseq, W, spt, sflag); }
+            HIPC(c, hipGetLastError());
+            ORIP_TRY(orip_runs_to_polys(c, spt, sflag, MS, cleaned.p));
+        }
+        // ---- A7
+        ORIP_TRY(split_small(c, cleaned.p, P, lines2.p, TOUT.xy, nt0, &nt2));
+    }
+    TOUT.n = nt0 + nt2;
+    // ---- B
+    DPolys* fin = &lines2.p;
+    const int64_t n2 = lines2.p.n;
+    if (P.post_on && n2 > 0) {
+        if (n2 > 0x3fffffff) ORIP_FAIL(c, "too many lines");
+        const int Wp = W + 2 * PAD8, Hp = H + 2 * PAD8; const size_t Np = (size_t)Wp * Hp;
+        if (Np >= (1ull << 27)) ORIP_FAIL(c, "canvas too large for stage 08-B index packing");
+        const int exp = P.post_brush * 2 + 6, rad = std::max(1, P.post_brush) / 2;
+        HIPC(c, c->vtmp[6].ensure((size_t)n2 * sizeof(PolyFeat) + (size_t)(n2 + 1) * (4 + 4 + 4) + (size_t)n2 * sizeof(GroupInfo) + 256));
+        PolyFeat* f2 = c->vtmp[6].as<PolyFeat>(); int* par = (int*)(f2 + n2); unsigned* is_root = (unsigned*)(par + (n2 + 1)); unsigned* root_scan = is_root + (n2 + 1);
+        GroupInfo* grp = (GroupInfo*)(root_scan + (n2 + 1) + ((3 * (n2 + 1)) & 1));
+        hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n2, 128)), dim3(128), 0, c->stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, 1, f2);
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, par, (int)n2);
+        { ProfScope ps(c, "k_bbox_pairs"); hipLaunchKernelGGL(k_bbox_pairs, dim3((unsigned)std::min<int64_t>(n2, 8192)), dim3(256), 0, c->stream, f2, (int)n2, exp, par); }
+        hipLaunchKernelGGL(k_group_init, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, grp, (int)n2);
+        hipLaunchKernelGGL(k_group_accum, dim3(cdiv(n2 + 1, 256)), dim3(256), 0, c->stream, f2, (int)n2, exp, par, grp, is_root);
+        ORIP_TRY(vscan_excl<unsigned>(c, is_root, root_scan, (size_t)n2 + 1));
+        hipLaunchKernelGGL(k_group_finish, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, f2, (int)n2, is_root, root_scan, grp);
+        // raster
+        HIPC(c, c->canvas.ensure(Np * 4 + 64));
+        unsigned* gid = c->canvas.as<unsigned>();
+        HIPC(c, hipMemsetAsync(gid, 0, Np * 4, c->stream));
+        { ProfScope ps(c, "k_stamp_groups"); hipLaunchKernelGGL(k_stamp_groups, dim3(8192), dim3(256), 0, c->stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, par, rad, gid, Wp, Hp); }
+        HIPC(c, c->vtmp[9].ensure(Np * 2 + 64));
+        u8* skA = c->vtmp[9].as<u8>(); u8* skB = skA + Np;
+        hipLaunchKernelGGL(k_gid_to_mask, dim3(cdiv(Np, 256)), dim3(256), 0, c->stream, gid, skA, Np);
+        int* d_changed = c->flags.as<int>() + 48;
+        dim3 g2(cdiv(Wp, 64), cdiv(Hp, 4)), blk(256);
+        for (int it = 0; it < 48; it++) {
+            HIPC(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, c->stream, skA, skB, Hp, Wp, 0, d_changed); }
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, c->stream, skB, skA, Hp, Wp, 1, d_changed); }
+            int ch = 0; ORIP_TRY(vread(c, &ch, d_changed));
+            if (!ch) break;
+        }
+        // components
+        HIPC(c, c->vtmp[10].ensure(Np * 4 + 64));
+        int* L2 = c->vtmp[10].as<int>();
+        hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, c->stream, skA, L2, Hp, Wp);
+        { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, c->stream, skA, L2, Hp, Wp); }
+        hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, c->stream, L2, (int)Np);
+        const int nblk = cdiv((int64_t)Np, 1024);
+        HIPC(c, c->vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
+        unsigned* bc = c->vtmp[0].as<unsigned>(); unsigned* bo = bc + (nblk + 1);
+        HIPC(c, hipMemsetAsync(bc + nblk, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_sk_count, dim3(nblk), blk, 0, c->stream, skA, (int64_t)Np, bc);
+        ORIP_TRY(vscan_excl<unsigned>(c, bc, bo, (size_t)nblk + 1));
+        unsigned M = 0; ORIP_TRY(vread(c, &M, bo + nblk));
+        if (M > 0) {
+            HIPC(c, c->vtmp[1].ensure((size_t)M * 16 + 64));
+            unsigned* kin = c->vtmp[1].as<unsigned>(); unsigned* lin_in = kin + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
+            hipLaunchKernelGGL(k_sk_write, dim3(nblk), blk, 0, c->stream, skA, L2, (int64_t)Np, bo, kin, lin_in);
+            ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, keys, lin_in, lin, (size_t)M, 0, 27)));
+            HIPC(c, c->vtmp[3].ensure((size_t)(M + 1) * 8 + 64));
+            unsigned* head = c->vtmp[3].as<unsigned>(); unsigned* hs = head + (M + 1);
+            hipLaunchKernelGGL(k_heads2, dim3(cdiv(M + 1, 256)), blk, 0, c->stream, keys, (int64_t)M, head);
+            ORIP_TRY(vscan_excl<unsigned>(c, head, hs, (size_t)M + 1));
+            unsigned NC = 0; ORIP_TRY(vread(c, &NC, hs + M));
+            HIPC(c, c->vtmp[4].ensure((size_t)(NC + 1) * (4 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)NC * sizeof(GatherDesc) + 256));
+            unsigned long long* ckin = c->vtmp[4].as<unsigned long long>(); unsigned long long* ckout = ckin + (NC + 1);
+            unsigned* cs = (unsigned*)(ckout + (NC + 1)); unsigned* cidx = cs + (NC + 2); unsigned* corder = cidx + (NC + 1); unsigned* outcnt = corder + (NC + 1);
+            unsigned* oflag = outcnt + (NC + 1); unsigned* oscan = oflag + (NC + 1); GatherDesc* pd = (GatherDesc*)(oscan + (NC + 1) + ((6 * (NC + 1) + 1) & 1) + 2);
+            hipLaunchKernelGGL(k_comp_starts2, dim3(cdiv(M, 256)), blk, 0, c->stream, head, hs, (int64_t)M, cs, NC);
+            hipLaunchKernelGGL(k_nearest_anchor, dim3(cdiv(M, 256)), blk, 0, c->stream, lin, (int64_t)M, gid, Wp, grp);
+            hipLaunchKernelGGL(k_comp_keys, dim3(cdiv(NC, 128)), dim3(128), 0, c->stream, cs, NC, lin, gid, Wp, grp, ckin, cidx);
+            ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cidx, corder, (size_t)NC, 0, 64)));
+            // per-component path, resample, RDP
+            HIPC(c, c->vtmp[5].ensure(Np * 8 + (size_t)M * (4 + 8 + 8 + 1 + 8) + 256));
+            BfsArrs B; B.sk = skA; B.seen = c->vtmp[5].as<unsigned>(); B.prev = (int*)(B.seen + Np); B.queue = B.prev + Np; B.Wp = Wp; B.Hp = Hp;
+            float2* fbuf = (float2*)(B.queue + M + (M & 1)); int2* stk = (int2*)(fbuf + M); int2* outpts = stk + M; uint8_t* keepb = (uint8_t*)(outpts + M);
+            HIPC(c, hipMemsetAsync(B.seen, 0, Np * 4, c->stream));
+            { ProfScope ps(c, "k_comp_paths"); hipLaunchKernelGGL(k_comp_paths, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, corder, NC, cs, keys, lin, gid, grp, B, P.post_minlen, P.post_step, (float)P.post_eps, fbuf, stk, keepb, outpts, outcnt); }
+            hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, c->stream, outcnt, NC, oflag);
+            ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
+            unsigned NP = 0; ORIP_TRY(vread(c, &NP, oscan + NC));
+            merged.p.n = 0; merged.p.total = 0;
+            HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, c->stream));
+            if (NP) {
+                hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, c->stream, corder, cs, outcnt, oflag, oscan, NC, pd);
+                ORIP_TRY(vgather(c, pd, NP, reinterpret_cast<const int32_t*>(outpts), merged.p));
+            }
+        } else { merged.p.n = 0; merged.p.total = 0; HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, c->stream)); }
+        HIPC(c, hipGetLastError());
+        fin = &merged.p;
+    }
+    // ---- C
+    return vreorder(c, *fin, OUT, 8);
+}

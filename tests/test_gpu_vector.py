@@ -118,3 +118,68 @@ def test_stage12_random_vs_oracle(dev, case):
             assert np.array_equal(a["points"], b["points"])
         else:
             assert (a["x"], a["y"]) == (b["x"], b["y"])
+
+
+def test_stage08_golden(dev, G):
+    from orip import stages as S
+    cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd)
+    for n in cfgd["color_names"]:
+        lines, taps = S.dedup_layer(unflat(G, f"sorted_{n}"), cfg, dev)
+        assert taps == _taps(G[f"taps_intra_{n}"]), n
+        assert same_polys(lines, unflat(G, f"lines_intra_{n}")), n
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_stage08_random_vs_oracle(dev, seed):
+    """Self-crossing random walks on a small canvas: exercises mask hits, hash hits, taps, clusters, anchors."""
+    from orip import stages as S
+    rng = np.random.default_rng(100 + seed)
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=[6, 8, 10][seed])
+    cfg = _cfgobj(cfgd)
+    W, H = O.canvas_size(cfgd)
+    polys = []
+    for _ in range([25, 60, 120][seed]):
+        m = int(rng.integers(2, 80))
+        p = (np.cumsum(rng.integers(-22, 23, (m, 2)), axis=0) + rng.integers(50, min(W, H) - 50, 2)).astype(np.int32)
+        if rng.random() < 0.25 and m > 3:
+            p[-1] = p[0]
+        polys.append(p.reshape(-1, 1, 2))
+    polys += [np.array([[5, 5], [9, 9], [14, 6]], np.int32).reshape(-1, 1, 2), np.array([[-40, 30], [60, 35], [90, -20]], np.int32).reshape(-1, 1, 2)]
+    want_l, want_t = O.stage08_layer(polys, O.derived08(cfgd))
+    got_l, got_t = S.dedup_layer(polys, cfg, dev)
+    assert got_t == want_t
+    assert same_polys(got_l, want_l), (len(got_l), len(want_l))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_full_chain_image_to_ops_matches_reference(dev, tag):
+    """Resident path 02 -> 12 from the image: final ops identical to the reference chain's ops.pkl."""
+    from orip import stages as S
+    G = load(f"golden_e2e_{tag}.npz")
+    cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd)
+    ops = S.run_path(G["img"], cfg, dev)
+    for n in cfgd["color_names"]:
+        got = [o["points"] if o["type"] == "line" else np.array([[o["x"], o["y"]]]) for o in ops[n]]
+        assert same_polys(got, unflat(G, f"ops_{n}")), n
+
+
+@pytest.mark.parametrize("case", [(256, 256, 4, 6), (384, 512, 8, 10)])
+def test_full_chain_vs_oracle(dev, case):
+    from orip import stages as S
+    from orip.synth import synth_image, layer_names
+    H, W, K, ppm = case
+    img = synth_image(H, W, K, seed=77)
+    cfgd = dict(O.DEFAULTS, color_names=layer_names(K), pixels_per_mm=ppm)
+    cfg = _cfgobj(cfgd)
+    want = O.run_pipeline(img, cfgd)
+    ops = S.run_path(img, cfg, dev)
+    for n in cfgd["color_names"]:
+        assert len(ops[n]) == len(want["ops"][n]), n
+        for a, b in zip(ops[n], want["ops"][n]):
+            assert a["type"] == b["type"]
+            if a["type"] == "line":
+                assert np.array_equal(a["points"], b["points"]), n
+            else:
+                assert (a["x"], a["y"]) == (b["x"], b["y"]), n
+    dg, tg = O.path_length(ops); dw, tw = O.path_length(want["ops"])
+    assert abs(dg + tg - dw - tw) <= 1e-3 * (dw + tw)      # north_star: plotted path length within 1e-3 relative
