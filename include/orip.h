@@ -81,6 +81,8 @@ int orip_extract_layers(orip_ctx* ctx, const float* centers /* [K,3] */, int K, 
                         float* centers_sorted_out /* [K,3] */, int64_t* counts_out /* [K] pixels per cluster */);
 int orip_get_labels(orip_ctx* ctx, uint8_t* labels_out);
 int orip_get_mask(orip_ctx* ctx, int layer, uint8_t* mask_out);
+/* layer sharding: keep only the listed cluster layers, compacted to local layers 0..n-1 (mask planes only) */
+int orip_keep_layers(orip_ctx* ctx, const int32_t* layers, int n);
 /* upload K masks [K,H,W] (stage 03 run stand-alone from mask.png files, 03:15-19) */
 int orip_set_masks(orip_ctx* ctx, const uint8_t* masks, int K, int H, int W);
 

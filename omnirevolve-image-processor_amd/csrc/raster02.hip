@@ -554,3 +554,14 @@ extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, i
     HIPC(c, hipMemcpyAsync(c->masks.p, masks, (size_t)H * W * K, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
+
+extern "C" int orip_keep_layers(orip_ctx* c, const int32_t* layers, int n) {
+    if (!c->masks.p || n < 1 || n > c->K) ORIP_FAIL(c, "bad layer subset (n=%d, K=%d)", n, c->K);
+    size_t plane = (size_t)c->H * c->W;
+    for (int i = 0; i < n; i++) {
+        if (layers[i] < i || layers[i] >= c->K || (i && layers[i] <= layers[i - 1])) ORIP_FAIL(c, "layer subset must be strictly increasing and within range");
+        if (layers[i] != i) HIPC(c, hipMemcpyAsync(c->masks.as<u8>() + plane * i, c->masks.as<u8>() + plane * layers[i], plane, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->K = n;
+    return 0;
+}

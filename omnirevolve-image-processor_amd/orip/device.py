@@ -110,6 +110,11 @@ class Device:
         self._ck(self.L.orip_set_masks(self.h, _p(m), self.K, self.H, self.W))
         self.sync()
 
+    def keep_layers(self, layers: Sequence[int]):
+        a = np.ascontiguousarray(np.asarray(list(layers), np.int32))
+        self._ck(self.L.orip_keep_layers(self.h, _p(a), len(a)))
+        self.K = len(a)
+
     # ---- stage 03
     def detect_edges(self, morph_k=3, open_iters=1, close_iters=1, gauss_k=3, low=50, high=150):
         self._ck(self.L.orip_detect_edges(self.h, morph_k, open_iters, close_iters, gauss_k, int(low), int(high)))

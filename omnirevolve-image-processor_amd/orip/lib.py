@@ -38,6 +38,7 @@ SIGNATURES = {
     "orip_kmeans_fit": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _P(_f64)]),
     "orip_extract_layers": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "orip_get_labels": (_i32, [_vp, _vp]), "orip_get_mask": (_i32, [_vp, _i32, _vp]), "orip_set_masks": (_i32, [_vp, _vp, _i32, _i32, _i32]),
+    "orip_keep_layers": (_i32, [_vp, _vp, _i32]),
     "orip_detect_edges": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "orip_get_edges": (_i32, [_vp, _i32, _vp]), "orip_set_edges": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "orip_find_contours": (_i32, [_vp]), "orip_get_skeleton": (_i32, [_vp, _i32, _vp]),

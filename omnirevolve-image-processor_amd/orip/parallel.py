@@ -1,0 +1,122 @@
+"""Multi-GPU layout of the path: one process per GPU, torch.distributed as plumbing only.
+
+The path shards by COLOUR LAYER.  Stage 02 (k-means fit on the fixed-seed subsample + assignment) is deterministic and
+cheap, so every rank runs it on the whole image instead of row-sharding it and all-gathering the label map.  From the
+mask morphology through stage 08 every layer is independent (03:45, 04:234, 05:114, 07:99, 08:561), so rank r owns the
+cluster layers {l : l % world == r}.  Stage 10 walks the layers dark->light against ONE cumulative raster
+(10:215,236-267) -- the only real exchange step of the path: the per-layer (lines_intra, taps_intra) lists are
+all-gathered (RCCL all_gather over xGMI with backend "nccl"; gloo in the CPU tests), stage 10 is then replicated on
+every rank (deterministic), and each rank orders (stage 12) the layers it owns.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+Lists = Tuple[List[np.ndarray], List[Tuple[int, int]]]
+
+
+def owned_layers(K: int, rank: int, world: int) -> List[int]:
+    return [l for l in range(K) if l % world == rank]
+
+
+def pack_layers(local: Dict[int, Lists], K: int) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (sizes int64 [K,3] = (#lines, #points, #taps) rows of owned layers, payload int32 flat)."""
+    sizes = np.zeros((K, 3), np.int64)
+    parts: List[np.ndarray] = []
+    for l in sorted(local):
+        lines, taps = local[l]
+        flat = [np.asarray(p).reshape(-1, 2).astype(np.int32) for p in lines]
+        lens = np.array([len(p) for p in flat], np.int32)
+        pts = np.concatenate(flat, 0).reshape(-1) if flat else np.zeros(0, np.int32)
+        tp = np.asarray(list(taps), np.int32).reshape(-1)
+        sizes[l] = (len(flat), len(pts) // 2, len(tp) // 2)
+        parts += [lens, pts.astype(np.int32), tp]
+    payload = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+    return sizes, payload
+
+
+def unpack_layers(sizes: np.ndarray, payloads: Sequence[np.ndarray], K: int, world: int) -> Dict[int, Lists]:
+    out: Dict[int, Lists] = {}
+    for r in range(world):
+        buf = payloads[r]; pos = 0
+        for l in owned_layers(K, r, world):
+            nl, npts, nt = (int(v) for v in sizes[l])
+            lens = buf[pos:pos + nl]; pos += nl
+            pts = buf[pos:pos + 2 * npts].reshape(-1, 2); pos += 2 * npts
+            tp = buf[pos:pos + 2 * nt].reshape(-1, 2); pos += 2 * nt
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            out[l] = ([pts[off[i]:off[i + 1]].reshape(-1, 1, 2).copy() for i in range(nl)], [(int(x), int(y)) for x, y in tp])
+    return out
+
+
+def exchange_layer_lists(local: Dict[int, Lists], K: int, device=None) -> Dict[int, Lists]:
+    """All-gather(v) of the per-layer (lines, taps) lists: sizes first (all_reduce of a [K,3] table whose rows are written by
+    the owning rank only), then one padded int32 payload per rank (all_gather).  `device`: torch device of the collective
+    buffers ("cuda:<local_rank>" for RCCL, "cpu" for gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return dict(local)
+    dev = torch.device(device if device is not None else "cpu")
+    sizes, payload = pack_layers(local, K)
+    t_sizes = torch.from_numpy(sizes).to(dev)
+    dist.all_reduce(t_sizes, op=dist.ReduceOp.SUM)
+    sizes = t_sizes.cpu().numpy()
+    per_rank = [int(sum(sizes[l, 0] + 2 * sizes[l, 1] + 2 * sizes[l, 2] for l in owned_layers(K, r, world))) for r in range(world)]
+    cap = max(1, max(per_rank))
+    send = torch.zeros(cap, dtype=torch.int32, device=dev)
+    if len(payload):
+        send[:len(payload)] = torch.from_numpy(payload).to(dev)
+    recv = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(world)]
+    dist.all_gather(recv, send)
+    payloads = [recv[r][:per_rank[r]].cpu().numpy() for r in range(world)]
+    return unpack_layers(sizes, payloads, K, world)
+
+
+def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None):
+    """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  Ops stay on the GPU."""
+    from . import lib as _l
+    from . import stages as S
+    from .config import scale_factors
+
+    names = list(cfg.color_names)
+    K = max(2, len(names))
+    lnames = S.cluster_names(cfg)[:K]
+    centers, _ = dev.kmeans_fit(S.subsample_indices(H * W), K)
+    dev.extract_layers(centers, want_counts=False)
+    mine = owned_layers(K, rank, world)
+    if world > 1:
+        if not mine:
+            mine_local = []
+        else:
+            dev.keep_layers(mine)
+            mine_local = list(range(len(mine)))
+    else:
+        mine_local = list(range(K))
+    if mine_local:
+        S._detect_edges_resident(dev, cfg)
+        dev.find_contours()
+        sx, sy, dx, dy = scale_factors(cfg, W, H)
+        p8 = S.params08(cfg)
+        for l in mine_local:
+            dev.scale_vectors(l, sx, sy, dx, dy)
+            dev.sort_contours(l)
+            dev.dedup_layer(l, p8)
+    if world > 1:
+        local = {g: (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i)) for i, g in enumerate(mine)}
+        allv = exchange_layer_lists(local, K, coll_device)
+        dev.set_layer_count(K)
+        for g in range(K):
+            dev.set_polys(_l.SLOT_LINES_INTRA, g, allv[g][0])
+            dev.set_taps(_l.TAPS_INTRA, g, allv[g][1])
+    order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
+    dev.dedup_cross(order, S.params10(cfg))
+    R = S.r_insert12(cfg)
+    n_ops = 0
+    for g in (mine if world > 1 else range(K)):
+        n_ops += len(dev.plot_order(g, R))
+    return n_ops

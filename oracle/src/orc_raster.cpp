@@ -352,28 +352,32 @@ void canny(const u8* src, u8* dst, int H, int W, int low, int high) {
 // offs[i] = (dy,dx) of P2..P9.
 // ----------------------------------------------------------------------------------------------
 static int zs_generic(u8* img /*0/1*/, int H, int W, const int offs[8][2], int max_iter) {
-    std::vector<size_t> del;
+    // examines only the current foreground pixels (kept as a list in raster order); same deletions as a full-image pass
+    std::vector<uint32_t> act, nxt; std::vector<size_t> del;
+    for (size_t i = 0; i < (size_t)H * W; i++) if (img[i]) act.push_back((uint32_t)i);
     auto get = [&](int y, int x) -> int { return (y < 0 || y >= H || x < 0 || x >= W) ? 0 : img[(size_t)y * W + x]; };
     int it = 0; bool changed = true;
     while (changed && it < max_iter) {
         it++; changed = false;
         for (int sub = 0; sub < 2; sub++) {
-            del.clear();
-            for (int y = 0; y < H; y++)
-                for (int x = 0; x < W; x++) {
-                    if (!img[(size_t)y * W + x]) continue;
-                    int P[8];
-                    for (int i = 0; i < 8; i++) P[i] = get(y + offs[i][0], x + offs[i][1]);
-                    int B = 0; for (int i = 0; i < 8; i++) B += P[i];
-                    if (B < 2 || B > 6) continue;
+            del.clear(); nxt.clear();
+            for (uint32_t idx : act) {
+                int y = (int)(idx / W), x = (int)(idx % W);
+                int P[8];
+                for (int i = 0; i < 8; i++) P[i] = get(y + offs[i][0], x + offs[i][1]);
+                int B = 0; for (int i = 0; i < 8; i++) B += P[i];
+                bool kill = false;
+                if (B >= 2 && B <= 6) {
                     int A = 0; for (int i = 0; i < 8; i++) A += (P[i] == 0 && P[(i + 1) & 7] == 1);
-                    if (A != 1) continue;
-                    int P2 = P[0], P4 = P[2], P6 = P[4], P8 = P[6];
-                    bool c = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0)
-                                      : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
-                    if (c) del.push_back((size_t)y * W + x);
+                    if (A == 1) {
+                        int P2 = P[0], P4 = P[2], P6 = P[4], P8 = P[6];
+                        kill = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0) : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
+                    }
                 }
+                if (kill) del.push_back(idx); else nxt.push_back(idx);
+            }
             if (!del.empty()) { changed = true; for (size_t i : del) img[i] = 0; }
+            act.swap(nxt);
         }
     }
     return it;

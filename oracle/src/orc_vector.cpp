@@ -31,10 +31,31 @@ static inline bool in_capsule(int64_t px, int64_t py, int64_t ax, int64_t ay, in
 void stamp_capsule(u8* mask, int H, int W, int x0, int y0, int x1, int y1, int r, u8 val) {
     int bx0 = std::max(0, std::min(x0, x1) - r), bx1 = std::min(W - 1, std::max(x0, x1) + r);
     int by0 = std::max(0, std::min(y0, y1) - r), by1 = std::min(H - 1, std::max(y0, y1) + r);
+    if (bx0 > bx1 || by0 > by1) return;
     int64_t r2 = (int64_t)r * r;
-    for (int y = by0; y <= by1; y++)
-        for (int x = bx0; x <= bx1; x++)
-            if (in_capsule(x, y, x0, y0, x1, y1, r2)) mask[(size_t)y * W + x] = val;
+    // The capsule is convex, so its intersection with a pixel row is one interval.  It is found with the SAME exact
+    // integer predicate as the plain double loop (which this replaces for speed only): an inside pixel is searched next
+    // to the point of the segment closest to the row, then both interval ends are bisected.
+    for (int y = by0; y <= by1; y++) {
+        double xc;
+        if ((y0 <= y && y <= y1) || (y1 <= y && y <= y0)) xc = (y1 == y0) ? 0.5 * (x0 + x1) : x0 + (double)(x1 - x0) * (double)(y - y0) / (double)(y1 - y0);
+        else xc = (std::abs(y - y0) < std::abs(y - y1)) ? x0 : x1;
+        int seed = -1;
+        if (y1 == y0 && y == y0) { int lo = std::max(bx0, std::min(x0, x1)), hi = std::min(bx1, std::max(x0, x1)); if (lo <= hi) seed = lo; }
+        if (seed < 0) {
+            int f = (int)std::floor(xc);
+            for (int cnd = f - 1; cnd <= f + 2; cnd++) { if (cnd < bx0 || cnd > bx1) continue; if (in_capsule(cnd, y, x0, y0, x1, y1, r2)) { seed = cnd; break; } }
+        }
+        if (seed < 0) {  // the closest point may lie outside the clipped box: fall back to the exact scan of this row
+            for (int x = bx0; x <= bx1; x++) if (in_capsule(x, y, x0, y0, x1, y1, r2)) { seed = x; break; }
+            if (seed < 0) continue;
+        }
+        int lo = bx0, hi = seed;       // smallest inside x in [bx0, seed]
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (in_capsule(mid, y, x0, y0, x1, y1, r2)) hi = mid; else lo = mid + 1; }
+        int xl = lo; lo = seed; hi = bx1;   // largest inside x in [seed, bx1]
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (in_capsule(mid, y, x0, y0, x1, y1, r2)) lo = mid; else hi = mid - 1; }
+        memset(mask + (size_t)y * W + xl, val, (size_t)(lo - xl + 1));
+    }
 }
 
 void stamp_disc(u8* mask, int H, int W, int cx, int cy, int r, u8 val) {
@@ -552,23 +573,35 @@ void post_skeleton_merge(const PolyList& lines, const Params08& P, PolyList& mer
         if (!any) continue;
         std::vector<int32_t> lab((size_t)h * w);
         int num = ccl8(sk.data(), lab.data(), h, w);
+        std::vector<int32_t> skpix;   // skeleton pixels in raster order
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) if (sk[(size_t)y * w + x]) { skpix.push_back(y); skpix.push_back(x); }
         auto nearest = [&](int xa, int ya, int& oy, int& ox) {
             int64_t best = INT64_MAX; oy = ox = -1;
-            for (int y = 0; y < h; y++)
-                for (int x = 0; x < w; x++) {
-                    if (!sk[(size_t)y * w + x]) continue;
-                    int64_t dy = (int64_t)y - (ya - y0), dx = (int64_t)x - (xa - x0), d = dy * dy + dx * dx;
-                    if (d < best) { best = d; oy = y; ox = x; }
-                }
+            for (size_t i = 0; i < skpix.size(); i += 2) {
+                int64_t dy = (int64_t)skpix[i] - (ya - y0), dx = (int64_t)skpix[i + 1] - (xa - x0), d = dy * dy + dx * dx;
+                if (d < best) { best = d; oy = skpix[i]; ox = skpix[i + 1]; }
+            }
         };
         int a0y_, a0x_, a1y_, a1x_;
         nearest(a0x, a0y, a0y_, a0x_); nearest(a1x, a1y, a1y_, a1x_);
-        std::vector<u8> comp((size_t)h * w);
+        // per-component bounding boxes, so that each component is examined on its own crop (same result as the
+        // reference's full-ROI `lab == cc` image: BFS order and the raster-first seed are invariant under cropping)
+        std::vector<int> cbx0(num + 1, w), cby0(num + 1, h), cbx1(num + 1, -1), cby1(num + 1, -1);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int l = lab[(size_t)y * w + x]; if (!l) continue;
+                cbx0[l] = std::min(cbx0[l], x); cbx1[l] = std::max(cbx1[l], x); cby0[l] = std::min(cby0[l], y); cby1[l] = std::max(cby1[l], y);
+            }
+        std::vector<u8> comp;
         std::vector<int32_t> path;
         for (int cc = 1; cc <= num; cc++) {
-            for (size_t i = 0; i < comp.size(); i++) comp[i] = lab[i] == cc ? 255 : 0;
-            bool ha = a0y_ >= 0 && comp[(size_t)a0y_ * w + a0x_], hb = a1y_ >= 0 && comp[(size_t)a1y_ * w + a1x_];
-            component_best_path(comp.data(), h, w, ha, a0y_, a0x_, hb, a1y_, a1x_, P.post_minlen, path);
+            int ox = cbx0[cc], oy = cby0[cc], cw = cbx1[cc] - cbx0[cc] + 1, chh = cby1[cc] - cby0[cc] + 1;
+            comp.assign((size_t)cw * chh, 0);
+            for (int y = 0; y < chh; y++) for (int x = 0; x < cw; x++) comp[(size_t)y * cw + x] = lab[(size_t)(y + oy) * w + x + ox] == cc ? 255 : 0;
+            auto inside = [&](int yy, int xx) { return yy >= oy && yy < oy + chh && xx >= ox && xx < ox + cw && comp[(size_t)(yy - oy) * cw + (xx - ox)]; };
+            bool ha = a0y_ >= 0 && inside(a0y_, a0x_), hb = a1y_ >= 0 && inside(a1y_, a1x_);
+            component_best_path(comp.data(), chh, cw, ha, a0y_ - oy, a0x_ - ox, hb, a1y_ - oy, a1x_ - ox, P.post_minlen, path);
+            for (size_t i = 0; i < path.size(); i += 2) { path[i] += oy; path[i + 1] += ox; }
             size_t pl = path.size() / 2;
             if (pl < 2) continue;
             std::vector<float> arr(2 * pl);
