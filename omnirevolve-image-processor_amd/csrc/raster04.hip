@@ -131,11 +131,17 @@ __global__ __launch_bounds__(256) void k_clear_visited(u8* __restrict__ st, cons
 // ------------------------------------------------------------------------------------------------
 #include "walker.h"
 
+// one wavefront per component; wave i takes component comp_order[i] (largest components first, so the long serial
+// chains start immediately and the small ones fill in behind them)
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_walk(WalkArgs A) {
-    unsigned c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= A.nc) return;
-    walk_component<WRITE>(A, c);
+    unsigned i = blockIdx.x;
+    if (i >= A.nc) return;
+    walk_component<WRITE>(A, A.comp_order ? A.comp_order[i] : i);
+}
+__global__ __launch_bounds__(256) void k_comp_sizes(const unsigned* __restrict__ cs, unsigned nc, unsigned* __restrict__ size, unsigned* __restrict__ idx) {
+    unsigned c = blockIdx.x * 256 + threadIdx.x;
+    if (c < nc) { size[c] = cs[c + 1] - cs[c]; idx[c] = c; }
 }
 
 // one block per descriptor (grid-stride): dst[pos + j] = dst[pos - lam + (j % lam)]
@@ -255,7 +261,19 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     unsigned* comp_paths = (unsigned*)(pts_base + (NC + 1)); unsigned* path_base = comp_paths + (NC + 1);
     HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, c->stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, c->stream));
     A.comp_pts = comp_pts; A.comp_paths = comp_paths; A.pts_base = pts_base; A.path_base = path_base;
-    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, A); }
+    {   // schedule: components by size, descending
+        HIPC(c, c->vtmp[5].ensure((size_t)NC * 16 + 64));
+        unsigned* szin = c->vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
+        hipLaunchKernelGGL(k_comp_sizes, dim3(cdiv(NC, 256)), block, 0, c->stream, comp_start, NC, szin, idin);
+        size_t bytes = 0;
+        HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, c->stream));
+        HIPC(c, c->tmpF.ensure(bytes + 16));
+        HIPC(c, rocprim::radix_sort_pairs_desc(c->tmpF.p, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, c->stream));
+        HIPC(c, c->vtmp[3].ensure((size_t)NC * 4 + 64));
+        HIPC(c, hipMemcpyAsync(c->vtmp[3].p, idout, (size_t)NC * 4, hipMemcpyDeviceToDevice, c->stream));
+        A.comp_order = c->vtmp[3].as<unsigned>();
+    }
+    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(NC), dim3(64), 0, c->stream, A); }
     HIPC(c, hipGetLastError());
     ORIP_TRY(excl_scan<unsigned long long>(c, comp_pts, pts_base, (size_t)NC + 1, c->tmpF));
     ORIP_TRY(excl_scan<unsigned>(c, comp_paths, path_base, (size_t)NC + 1, c->tmpF));
@@ -280,7 +298,7 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     A.desc = c->vtmp[5].as<unsigned long long>(); A.desc_cap = M;
     A.n_desc = (unsigned*)(c->flags.as<int>() + 16);
     HIPC(c, hipMemsetAsync(A.n_desc, 0, 4, c->stream));
-    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, A); }
+    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(NC), dim3(64), 0, c->stream, A); }
     { ProfScope ps(c, "k_expand_cycles"); hipLaunchKernelGGL(k_expand_cycles, dim3(4096), block, 0, c->stream, A.desc, A.n_desc, A); }
     HIPC(c, hipGetLastError());
     return 0;

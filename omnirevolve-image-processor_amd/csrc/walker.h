@@ -1,6 +1,12 @@
 // csrc/walker.h -- the centerline walker of stage 04 (04_find_contours.py trace_centerlines, 04:137-205).
-// Shared verbatim by the HIP kernel k_walk (raster04.hip) and by tests/host/walk_harness.cpp, which compiles
-// this header with g++ to unit-test the serial walk logic on the CPU (test infrastructure; not a product path).
+//
+// One WAVEFRONT walks one connected component with the reference's exact serial semantics:
+//   * the 8 neighbours of the current pixel are probed by lanes 0..7 in one load each; the NEIGH8-ordered choice is a
+//     ballot + find-first-set, so a step costs one memory round trip instead of up to eight dependent ones;
+//   * the raster-ordered scans for the next endpoint / leftover pixel test 64 list entries per step (ballot);
+//   * every decision is taken from wave-uniform values (ballot masks, broadcasts), lane 0 does all stores.
+// The same source is compiled with g++ by tests/host/walk_harness.cpp, where a "wave" is emulated by plain loops, so
+// the walk logic (phases, guards, cycle fast-forward) is unit-tested on the CPU as well (test infrastructure).
 #pragma once
 #include <cstdint>
 #include "../../include/orip.h"
@@ -8,11 +14,6 @@
 #define ORIP_HD __host__ __device__
 #else
 #define ORIP_HD
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ORIP_FETCH_INC(p) atomicAdd((p), 1u)
-#else
-#define ORIP_FETCH_INC(p) ((*(p))++)
 #endif
 typedef uint8_t u8;
 #define ST_FG 1
@@ -22,7 +23,7 @@ typedef uint8_t u8;
 
 struct WalkArgs {
     int H, W; int64_t plane;
-    u8* st;                            // [K,H,W]
+    u8* st;                            // [K,H,W] state bytes
     const unsigned* keys; const unsigned* lin; const unsigned* comp_start; unsigned nc;
     long long total_fg[ORIP_MAX_LAYERS];
     // count pass outputs / write pass inputs
@@ -32,13 +33,73 @@ struct WalkArgs {
     int32_t* pts[ORIP_MAX_LAYERS]; int64_t* off[ORIP_MAX_LAYERS];
     // cycle expansion descriptors: (layer, dst point index, period, count)
     unsigned long long* desc; unsigned* n_desc; unsigned desc_cap;
+    const unsigned* comp_order;        // optional: component processed by wave i (largest first), or nullptr
 };
 
+namespace walk_detail {
+#if defined(__HIP_DEVICE_COMPILE__)
+struct Wave {
+    int lane;
+    __device__ Wave() : lane((int)(threadIdx.x & 63)) {}
+    __device__ bool leader() const { return lane == 0; }
+    // probe the 8 neighbours of (px,py); returns masks over NEIGH8 indices
+    __device__ void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) const {
+        const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        u8 v = 0; bool any = false;
+        if (lane < 8) {
+            int xx = px + dxs[lane], yy = py + dys[lane];
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) { v = st[(size_t)yy * W + xx]; any = (v & ST_FG) && !(xx == pvx && yy == pvy); }
+        }
+        myv = v;
+        m_any = (unsigned)(__ballot(any) & 0xffu);
+        m_unvis = (unsigned)(__ballot(any && !(v & ST_VIS)) & 0xffu);
+    }
+    __device__ u8 value_of(u8 myv, int k) const { return (u8)__shfl((int)myv, k, 64); }
+    // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
+    __device__ unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
+        for (unsigned q = q0; q < e; q += 64) {
+            unsigned qq = q + lane; bool ok = false;
+            if (qq < e) { u8 v = st[lin[qq]]; ok = ((v & need) == need) && !(v & ST_VIS); }
+            unsigned long long m = __ballot(ok);
+            if (m) return q + (unsigned)(__ffsll((long long)m) - 1);
+        }
+        return e;
+    }
+    __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
+    __device__ unsigned fetch_inc(unsigned* p) const { unsigned r = 0; if (lane == 0) r = atomicAdd(p, 1u); return (unsigned)__shfl((int)r, 0, 64); }
+};
+#else
+struct Wave {
+    u8 nv[8];
+    bool leader() const { return true; }
+    void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
+        const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        m_any = m_unvis = 0; myv = 0;
+        for (int k = 0; k < 8; k++) {
+            int xx = px + dxs[k], yy = py + dys[k]; nv[k] = 0;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            u8 v = st[(size_t)yy * W + xx]; nv[k] = v;
+            if ((v & ST_FG) && !(xx == pvx && yy == pvy)) { m_any |= 1u << k; if (!(v & ST_VIS)) m_unvis |= 1u << k; }
+        }
+    }
+    u8 value_of(u8, int k) const { return nv[k]; }
+    unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
+        for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) return q; }
+        return e;
+    }
+    void fence() const {}
+    unsigned fetch_inc(unsigned* p) const { return (*p)++; }
+};
+#endif
+ORIP_HD inline int ffs8(unsigned m) { int k = 0; while (!((m >> k) & 1u)) k++; return k; }
+}  // namespace walk_detail
 
 template <bool WRITE>
 ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
+    using namespace walk_detail;
     const int NBX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};   // NEIGH8 (dx,dy), 04:12
     const int NBY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    Wave wv;
     const unsigned b = A.comp_start[c], e = A.comp_start[c + 1];
     const int layer = (int)(A.keys[b] >> 26);
     u8* st = A.st + A.plane * layer;
@@ -54,30 +115,24 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
     }
     // Paths shorter than 5 points are dropped after the fact, so their points must never land outside this component's own
     // output range [wpos0, wend) (the range holds exactly the kept paths; anything inside it is overwritten by a later kept path).
-    auto emit = [&](unsigned long long pos, int x, int y) { if (WRITE && pos < wend) { out[2 * pos] = x; out[2 * pos + 1] = y; } };
+    auto emit = [&](unsigned long long pos, int x, int y) { if (WRITE && pos < wend && wv.leader()) { out[2 * pos] = x; out[2 * pos + 1] = y; } };
+    auto mark = [&](size_t j, u8 v) { if (wv.leader()) st[j] = (u8)(v | ST_VIS); };
     // ---- phase 1: walks from endpoints (04:144-171)
-    for (unsigned q = b; q < e; q++) {
+    for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG | ST_END); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG | ST_END)) {
         unsigned s = A.lin[q];
-        u8 sv = st[s];
-        if (!(sv & ST_END) || (sv & ST_VIS)) continue;
         int px = (int)(s % W), py = (int)(s / W), pvx = -1, pvy = -1;
         unsigned long long len = 1; emit(wpos, px, py);
-        st[s] = sv | ST_VIS;
+        mark(s, ST_FG | ST_END); wv.fence();
         long long guard = 0;
         while (true) {
-            int nx = -1, ny = -1;
-            for (int k = 0; k < 8; k++) {
-                int xx = px + NBX[k], yy = py + NBY[k];
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                u8 v = st[(size_t)yy * W + xx];
-                if (!(v & ST_FG) || (v & ST_VIS)) continue;
-                if (xx == pvx && yy == pvy) continue;
-                nx = xx; ny = yy; break;
-            }
-            if (nx < 0) break;
+            unsigned m_any, m_unvis; u8 myv;
+            wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
+            if (!m_unvis) break;
+            int k = ffs8(m_unvis);
+            int nx = px + NBX[k], ny = py + NBY[k];
+            u8 v = wv.value_of(myv, k);
             emit(wpos + len, nx, ny); len++;
-            size_t j = (size_t)ny * W + nx;
-            u8 v = st[j]; st[j] = v | ST_VIS;
+            mark((size_t)ny * W + nx, v); wv.fence();
             pvx = px; pvy = py; px = nx; py = ny;
             if (v & (ST_JUN | ST_END)) break;
             guard++;
@@ -85,40 +140,31 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
         }
         if (len >= 5) {   // >=2 to be a path (04:168) and >=5 to survive vectorize_layer (04:224)
             n_pts += len; n_paths++;
-            if (WRITE) { wpos += len; off[wpath + 1] = (int64_t)wpos; wpath++; }
+            if (WRITE) { wpos += len; if (wv.leader()) off[wpath + 1] = (int64_t)wpos; wpath++; }
         }
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
-    for (unsigned q = b; q < e; q++) {
+    for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG)) {
         unsigned s = A.lin[q];
-        u8 sv = st[s];
-        if (sv & ST_VIS) continue;
         const int x0 = (int)(s % W), y0 = (int)(s / W);
         int px = x0, py = y0, pvx = -1, pvy = -1;
         unsigned long long len = 1; emit(wpos, px, py);
-        st[s] = sv | ST_VIS;
+        { u8 sv = st[s]; mark(s, sv); wv.fence(); }
         long long guard = 0;
         // Brent cycle detection on the (prev,cur) state; reset whenever a fresh pixel is consumed
         int tpx = -2, tpy = -2, tcx = -2, tcy = -2; long long power = 1, lam = 0;
-        bool closed_on_start = false, expanded = false;
         while (true) {
-            int nx = -1, ny = -1, ax = -1, ay = -1;
-            for (int k = 0; k < 8; k++) {
-                int xx = px + NBX[k], yy = py + NBY[k];
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                u8 v = st[(size_t)yy * W + xx];
-                if (!(v & ST_FG)) continue;
-                if (xx == pvx && yy == pvy) continue;
-                if (ax < 0) { ax = xx; ay = yy; }
-                if (!(v & ST_VIS)) { nx = xx; ny = yy; break; }
-            }
-            bool fresh = nx >= 0;
-            if (!fresh) { nx = ax; ny = ay; }
-            if (nx < 0) break;
+            unsigned m_any, m_unvis; u8 myv;
+            wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
+            bool fresh = m_unvis != 0;
+            unsigned m = fresh ? m_unvis : m_any;
+            if (!m) break;
+            int k = ffs8(m);
+            int nx = px + NBX[k], ny = py + NBY[k];
             emit(wpos + len, nx, ny); len++;
-            if (fresh) { size_t j = (size_t)ny * W + nx; st[j] |= ST_VIS; }
+            if (fresh) { mark((size_t)ny * W + nx, wv.value_of(myv, k)); wv.fence(); }
             pvx = px; pvy = py; px = nx; py = ny;
-            if (px == x0 && py == y0) { closed_on_start = true; break; }
+            if (px == x0 && py == y0) break;
             guard++;
             if (guard > fg_comp * 4) break;
             if (fresh) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power = 1; lam = 0; }
@@ -130,37 +176,28 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
                     long long remaining = fg_comp * 4 + 1 - guard;
                     if (remaining > 0) {
                         if (WRITE) {
-                            unsigned slot = ORIP_FETCH_INC(A.n_desc);
-                            if (slot < A.desc_cap) {
+                            unsigned slot = wv.fetch_inc(A.n_desc);
+                            if (slot < A.desc_cap && wv.leader()) {
                                 unsigned long long* d = A.desc + 4ull * slot;
                                 d[0] = (unsigned long long)layer; d[1] = wpos + len; d[2] = (unsigned long long)lam; d[3] = (unsigned long long)remaining;
                             }
                         }
                         // position after the remaining steps = cycle point (remaining mod lam) steps ahead; needed for the closing test
                         long long adv = remaining % lam;
-                        if (adv) {
-                            // replay adv steps (no fresh pixels by construction)
-                            for (long long t = 0; t < adv; t++) {
-                                int bx = -1, by = -1;
-                                for (int k = 0; k < 8; k++) {
-                                    int xx = px + NBX[k], yy = py + NBY[k];
-                                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                                    if (!(st[(size_t)yy * W + xx] & ST_FG)) continue;
-                                    if (xx == pvx && yy == pvy) continue;
-                                    bx = xx; by = yy; break;
-                                }
-                                pvx = px; pvy = py; px = bx; py = by;
-                            }
+                        for (long long t = 0; t < adv; t++) {
+                            unsigned ma, mu; u8 mv;
+                            wv.probe(st, W, H, px, py, pvx, pvy, ma, mu, mv);
+                            int kk = ffs8(ma);
+                            int bx = px + NBX[kk], by = py + NBY[kk];
+                            pvx = px; pvy = py; px = bx; py = by;
                         }
                         len += (unsigned long long)remaining;
                     }
-                    expanded = true;
                     break;
                 }
                 if (lam == power) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power <<= 1; lam = 0; }
             }
         }
-        (void)closed_on_start; (void)expanded;
         if (len >= 2) {
             int ddx = x0 - px, ddy = y0 - py;
             if (ddx * ddx + ddy * ddy < 3) {   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}
@@ -168,10 +205,9 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
             }
             if (len >= 5) {
                 n_pts += len; n_paths++;
-                if (WRITE) { wpos += len; off[wpath + 1] = (int64_t)wpos; wpath++; }
+                if (WRITE) { wpos += len; if (wv.leader()) off[wpath + 1] = (int64_t)wpos; wpath++; }
             }
         }
     }
-    if (!WRITE) { A.comp_pts[c] = n_pts; A.comp_paths[c] = n_paths; }
+    if (!WRITE && wv.leader()) { A.comp_pts[c] = n_pts; A.comp_paths[c] = n_paths; }
 }
-

@@ -54,7 +54,7 @@ extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out,
     *n_paths = path_base[NC]; *n_pts = (int64_t)pts_base[NC];
     if (*n_paths + 1 > off_cap || *n_pts > pts_cap) return 1;
     for (unsigned i = 0; i < M; i++) st[lin[i]] &= (uint8_t)~ST_VIS;
-    std::vector<unsigned long long> desc((size_t)M * 4 + 4); unsigned n_desc = 0;
+    std::vector<unsigned long long> desc((size_t)M * 4 + 4); unsigned n_desc = 0; A.comp_order = nullptr;
     A.desc = desc.data(); A.n_desc = &n_desc; A.desc_cap = M;
     A.pts[0] = pts_out; A.off[0] = off_out;
     for (unsigned c = 0; c < NC; c++) walk_component<true>(A, c);
