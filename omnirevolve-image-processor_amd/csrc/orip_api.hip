@@ -1,6 +1,8 @@
 // csrc/orip_api.hip -- context life-cycle, slot transfers and profiling hooks of liborip.so.
 #include "orip_ctx.h"
 
+thread_local int orip_tls_lane = 0;
+
 extern "C" int orip_create(int device_id, orip_ctx** out) {
     if (!out) return -1;
     *out = nullptr;
@@ -10,11 +12,13 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return -4;
     orip_ctx* c = new orip_ctx();
     c->device = device_id;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
-    hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
-    if (c->flags.ensure(4096) != hipSuccess) { delete c; return -6; }
-    hipMemsetAsync(c->flags.p, 0, 4096, c->stream);
-    hipStreamSynchronize(c->stream);
+    for (auto& l : c->ln) {
+        if (hipStreamCreate(&l.stream) != hipSuccess) { delete c; return -5; }
+        hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
+        if (l.flags.ensure(4096) != hipSuccess) { delete c; return -6; }
+        hipMemsetAsync(l.flags.p, 0, 4096, l.stream);
+        hipStreamSynchronize(l.stream);
+    }
     *out = c;
     return 0;
 }
@@ -22,24 +26,26 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
 extern "C" void orip_destroy(orip_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->tmpE, &c->tmpF,
-                    &c->lab_tabs, &c->flags, &c->canvas};
+    hipDeviceSynchronize();
+    DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->lab_tabs};
     for (DBuf* b : bufs) b->release();
-    for (auto& v : c->vtmp) v.release();
+    for (auto& l : c->ln) {
+        l.tmpE.release(); l.tmpF.release(); l.flags.release(); l.canvas.release();
+        for (auto& v : l.vtmp) v.release();
+        if (l.ev0) hipEventDestroy(l.ev0);
+        if (l.ev1) hipEventDestroy(l.ev1);
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
     for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); }
     for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" const char* orip_last_error(orip_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 extern "C" int orip_sync(orip_ctx* c) {
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 
@@ -72,9 +78,9 @@ extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, in
     ORIP_TRY(check_slot(c, slot, layer));
     DPolys& P = c->polys[slot][layer];
     if (P.n == 0) { off[0] = 0; return 0; }
-    HIPC(c, hipMemcpyAsync(off, P.off.p, (size_t)(P.n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    if (P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(off, P.off.p, (size_t)(P.n + 1) * 8, hipMemcpyDeviceToHost, LN(c).stream));
+    if (P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const int64_t* off, const int32_t* pts) {
@@ -84,10 +90,10 @@ extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const
     int64_t total = n ? off[n] : 0;
     HIPC(c, P.off.ensure((size_t)(n + 1) * 8 + 64));
     HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
-    if (n) HIPC(c, hipMemcpyAsync(P.off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    else HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
-    if (total) HIPC(c, hipMemcpyAsync(P.pts.p, pts, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    if (n) HIPC(c, hipMemcpyAsync(P.off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, LN(c).stream));
+    else HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
+    if (total) HIPC(c, hipMemcpyAsync(P.pts.p, pts, (size_t)total * 8, hipMemcpyHostToDevice, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     P.n = n; P.total = total;
     if (layer >= c->K) c->K = layer + 1;
     return 0;
@@ -101,15 +107,15 @@ extern "C" int orip_get_taps(orip_ctx* c, int which, int layer, int32_t* xy) {
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");
     DTaps& T = c->taps[which][layer];
     if (!T.n) return 0;
-    HIPC(c, hipMemcpyAsync(xy, T.xy.p, (size_t)T.n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(xy, T.xy.p, (size_t)T.n * 8, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_set_taps(orip_ctx* c, int which, int layer, int64_t n, const int32_t* xy) {
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS || n < 0) ORIP_FAIL(c, "bad taps slot");
     DTaps& T = c->taps[which][layer];
     HIPC(c, T.xy.ensure((size_t)std::max<int64_t>(n, 1) * 8 + 64));
-    if (n) { HIPC(c, hipMemcpyAsync(T.xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream)); HIPC(c, hipStreamSynchronize(c->stream)); }
+    if (n) { HIPC(c, hipMemcpyAsync(T.xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, LN(c).stream)); HIPC(c, hipStreamSynchronize(LN(c).stream)); }
     T.n = n;
     if (layer >= c->K) c->K = layer + 1;
     return 0;

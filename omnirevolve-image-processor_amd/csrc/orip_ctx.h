@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/orip.h"
 
 typedef uint8_t u8;
@@ -15,7 +16,7 @@ typedef uint8_t u8;
     do {                                                                 \
         char _b[512];                                                    \
         snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
-        (ctx)->err = std::string(__func__) + ": " + _b;                  \
+        { std::lock_guard<std::mutex> _g((ctx)->mu); (ctx)->err = std::string(__func__) + ": " + _b; } \
         return -1;                                                       \
     } while (0)
 
@@ -58,9 +59,23 @@ struct DTaps {
 
 struct ProfEntry { double ms = 0; int64_t launches = 0; };
 
+// Per-lane resources.  Lane 0 serves the raster stages and the cross-layer stage 10; lane l+1 serves the per-layer vector
+// stages (05, 07, 08, 12) of layer l, so that different layers can be driven concurrently from different host threads,
+// each on its own HIP stream with its own scratch (the serial kernels of one layer then overlap with those of the others).
+struct LaneRes {
+    hipStream_t stream = 0;
+    DBuf vtmp[12], tmpE, tmpF, flags, canvas;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DPolys tp[6];   // persistent temporaries of the vector stages (no hipFree in steady state: hipFree synchronises the device)
+};
+extern thread_local int orip_tls_lane;
+#define LN(c) ((c)->ln[orip_tls_lane])
+struct LaneGuard { int prev; explicit LaneGuard(int lane) : prev(orip_tls_lane) { orip_tls_lane = lane; } ~LaneGuard() { orip_tls_lane = prev; } };
+
 struct orip_ctx {
     int device = 0;
-    hipStream_t stream = 0;
+    LaneRes ln[ORIP_MAX_LAYERS + 1];
+    std::mutex mu;
     std::string err;
     // image / raster state
     int H = 0, W = 0, K = 0;
@@ -69,32 +84,28 @@ struct orip_ctx {
     DBuf masks;     // u8 [K,H,W]
     DBuf edges;     // u8 [K,H,W]
     DBuf skel;      // u8 [K,H,W]
-    DBuf tmpA, tmpB, tmpC, tmpD, tmpE, tmpF;   // scratch
+    DBuf tmpA, tmpB, tmpC, tmpD;   // raster scratch
     DBuf lab_tabs;  // u16 gamma[256] + u16 cbrt[3072] + i32 coeffs[9]
     bool tabs_ready = false;
-    DBuf flags;     // small int scratch (device), 256 ints
-    void* h_pinned = nullptr;  // 4 KB pinned host scratch
     // vector state
     DPolys polys[ORIP_SLOT_COUNT][ORIP_MAX_LAYERS];
     DTaps taps[2][ORIP_MAX_LAYERS];
     DBuf ops[ORIP_MAX_LAYERS];
     int64_t n_ops[ORIP_MAX_LAYERS] = {0};
-    DBuf canvas;    // stage 08 / 10 raster state
-    DBuf vtmp[12];  // vector-stage scratch
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 // Time one kernel launch with HIP events on ctx->stream when profiling is enabled (bench.py roofline leg).
 struct ProfScope {
     orip_ctx* c; const char* name;
-    ProfScope(orip_ctx* ctx, const char* n) : c(ctx), name(n) { if (c->prof_on) hipEventRecord(c->ev0, c->stream); }
+    ProfScope(orip_ctx* ctx, const char* n) : c(ctx), name(n) { if (c->prof_on) hipEventRecord(LN(c).ev0, LN(c).stream); }
     ~ProfScope() {
         if (!c->prof_on) return;
-        hipEventRecord(c->ev1, c->stream); hipEventSynchronize(c->ev1);
-        float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        hipEventRecord(LN(c).ev1, LN(c).stream); hipEventSynchronize(LN(c).ev1);
+        float ms = 0; hipEventElapsedTime(&ms, LN(c).ev0, LN(c).ev1);
+        std::lock_guard<std::mutex> g(c->mu);
         auto& e = c->prof[name]; e.ms += ms; e.launches++;
     }
 };

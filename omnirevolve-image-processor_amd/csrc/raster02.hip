@@ -33,8 +33,8 @@ int orip_raster02_lab_tables(orip_ctx* c) {
     const double D65[3] = {0.950456, 1.0, 1.088754};
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t.coef[i * 3 + j] = (int32_t)std::lrint(4096.0 * M[i * 3 + j] / D65[i]);
     HIPC(c, c->lab_tabs.ensure(sizeof(LabTabs)));
-    HIPC(c, hipMemcpyAsync(c->lab_tabs.p, &t, sizeof(LabTabs), hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(c->lab_tabs.p, &t, sizeof(LabTabs), hipMemcpyHostToDevice, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     c->tabs_ready = true;
     return 0;
 }
@@ -425,7 +425,7 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
         int kk = passes[i] < 0 ? 1 : k; unsigned long long ss = passes[i] < 0 ? 1ULL : se;
         {
             ProfScope ps(c, "k_morph_pass");
-            hipLaunchKernelGGL(k_morph_pass, grid, block, 0, c->stream, cur, out, H, W, kk, ss, passes[i] == 1 ? 1 : 0, lm ? 1 : 0);
+            hipLaunchKernelGGL(k_morph_pass, grid, block, 0, LN(c).stream, cur, out, H, W, kk, ss, passes[i] == 1 ? 1 : 0, lm ? 1 : 0);
         }
         cur = out; lm = false;
     }
@@ -441,7 +441,7 @@ extern "C" int orip_set_image(orip_ctx* c, const uint8_t* bgr, int H, int W) {
     ORIP_TRY(orip_raster02_lab_tables(c));
     c->H = H; c->W = W;
     HIPC(c, c->image.ensure((size_t)H * W * 3 + 16));
-    HIPC(c, hipMemcpyAsync(c->image.p, bgr, (size_t)H * W * 3, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->image.p, bgr, (size_t)H * W * 3, hipMemcpyHostToDevice, LN(c).stream));
     return 0;
 }
 
@@ -449,12 +449,12 @@ extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* 
     if (!c->image.p) ORIP_FAIL(c, "no image set");
     if (!idx) n = (int64_t)c->H * c->W;
     HIPC(c, c->tmpB.ensure((size_t)n * 3 + 16));
-    if (idx) { HIPC(c, c->tmpC.ensure((size_t)n * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, idx, (size_t)n * 8, hipMemcpyHostToDevice, c->stream)); }
-    hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(n, 256))), dim3(256), 0, c->stream, c->image.as<u8>(),
+    if (idx) { HIPC(c, c->tmpC.ensure((size_t)n * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, idx, (size_t)n * 8, hipMemcpyHostToDevice, LN(c).stream)); }
+    hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(n, 256))), dim3(256), 0, LN(c).stream, c->image.as<u8>(),
                        idx ? c->tmpC.as<int64_t>() : nullptr, n, c->tmpB.as<u8>(), c->lab_tabs.as<LabTabs>());
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(lab_out, c->tmpB.p, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(lab_out, c->tmpB.p, (size_t)n * 3, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 
@@ -465,34 +465,34 @@ extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n
     int64_t N = sample_idx ? n_idx : (int64_t)c->H * c->W;
     if (N < K || N > 0x7fffffff) ORIP_FAIL(c, "bad sample count %lld", (long long)N);
     HIPC(c, c->tmpB.ensure((size_t)N * 3 + 16));
-    if (sample_idx) { HIPC(c, c->tmpC.ensure((size_t)N * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, sample_idx, (size_t)N * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (sample_idx) { HIPC(c, c->tmpC.ensure((size_t)N * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, sample_idx, (size_t)N * 8, hipMemcpyHostToDevice, LN(c).stream)); }
     {
         ProfScope ps(c, "k_lab_gather");
-        hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(N, 256))), dim3(256), 0, c->stream, c->image.as<u8>(),
+        hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(N, 256))), dim3(256), 0, LN(c).stream, c->image.as<u8>(),
                            sample_idx ? c->tmpC.as<int64_t>() : nullptr, N, c->tmpB.as<u8>(), c->lab_tabs.as<LabTabs>());
     }
     HIPC(c, c->tmpD.ensure((size_t)N * 4 * 4 + 256));
     int32_t* base = c->tmpD.as<int32_t>();
-    HIPC(c, c->flags.ensure(1024));
+    HIPC(c, LN(c).flags.ensure(1024));
     attempts = std::max(attempts, 1);
     double epsilon = std::max(eps, 0.0); epsilon *= epsilon;
     int maxCount = std::min(std::max(max_iter, 2), 100);
     if (K == 1) { attempts = 1; maxCount = 2; }
-    float* d_centers = (float*)((char*)c->flags.p + 256);
-    double* d_comp = (double*)((char*)c->flags.p + 512);
-    int* d_status = (int*)c->flags.p;
-    HIPC(c, hipMemsetAsync(c->flags.p, 0xff, 4, c->stream));
+    float* d_centers = (float*)((char*)LN(c).flags.p + 256);
+    double* d_comp = (double*)((char*)LN(c).flags.p + 512);
+    int* d_status = (int*)LN(c).flags.p;
+    HIPC(c, hipMemsetAsync(LN(c).flags.p, 0xff, 4, LN(c).stream));
     {
         ProfScope ps(c, "k_kmeans_fit");
-        hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, c->stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
+        hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
                            base, base + N, base + 2 * N, base + 3 * N, d_centers, d_comp, d_status);
     }
     HIPC(c, hipGetLastError());
     struct { float cen[ORIP_MAX_LAYERS * 3]; } hc; double comp; int st;
-    HIPC(c, hipMemcpyAsync(hc.cen, d_centers, sizeof(float) * K * 3, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(&comp, d_comp, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(hc.cen, d_centers, sizeof(float) * K * 3, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipMemcpyAsync(&comp, d_comp, 8, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     if (st != 0) ORIP_FAIL(c, "kmeans kernel did not complete (status %d)", st);
     memcpy(centers_out, hc.cen, sizeof(float) * K * 3);
     if (compactness_out) *compactness_out = comp;
@@ -517,18 +517,18 @@ extern "C" int orip_extract_layers(orip_ctx* c, const float* centers, int K, int
     HIPC(c, c->masks.ensure((size_t)npx * K));
     {
         ProfScope ps(c, "k_lab_assign");
-        hipLaunchKernelGGL(k_lab_assign, dim3(std::min<int64_t>(4096, std::max<int64_t>(1, cdiv(npx / 4, 256)))), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_lab_assign, dim3(std::min<int64_t>(4096, std::max<int64_t>(1, cdiv(npx / 4, 256)))), dim3(256), 0, LN(c).stream,
                            c->image.as<u8>(), c->labels.as<u8>(), npx, c->lab_tabs.as<LabTabs>(), cs);
     }
     HIPC(c, hipGetLastError());
     if (counts_out) {
-        HIPC(c, c->flags.ensure(1024));
-        unsigned long long* d_cnt = (unsigned long long*)((char*)c->flags.p + 768);
-        HIPC(c, hipMemsetAsync(d_cnt, 0, ORIP_MAX_LAYERS * 8, c->stream));
-        hipLaunchKernelGGL(k_count_labels, dim3(1024), dim3(256), 0, c->stream, c->labels.as<u8>(), npx, d_cnt);
+        HIPC(c, LN(c).flags.ensure(1024));
+        unsigned long long* d_cnt = (unsigned long long*)((char*)LN(c).flags.p + 768);
+        HIPC(c, hipMemsetAsync(d_cnt, 0, ORIP_MAX_LAYERS * 8, LN(c).stream));
+        hipLaunchKernelGGL(k_count_labels, dim3(1024), dim3(256), 0, LN(c).stream, c->labels.as<u8>(), npx, d_cnt);
         unsigned long long h[ORIP_MAX_LAYERS];
-        HIPC(c, hipMemcpyAsync(h, d_cnt, ORIP_MAX_LAYERS * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpyAsync(h, d_cnt, ORIP_MAX_LAYERS * 8, hipMemcpyDeviceToHost, LN(c).stream));
+        HIPC(c, hipStreamSynchronize(LN(c).stream));
         for (int k = 0; k < K; k++) counts_out[k] = (int64_t)h[k];
     }
     return orip_morph_open_close(c, c->labels.as<u8>(), c->masks.as<u8>(), K, 0, 3, open_iters, close_iters, true);
@@ -536,22 +536,22 @@ extern "C" int orip_extract_layers(orip_ctx* c, const float* centers, int K, int
 
 extern "C" int orip_get_labels(orip_ctx* c, uint8_t* out) {
     if (!c->labels.p) ORIP_FAIL(c, "no labels resident");
-    HIPC(c, hipMemcpyAsync(out, c->labels.p, (size_t)c->H * c->W, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->labels.p, (size_t)c->H * c->W, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_get_mask(orip_ctx* c, int layer, uint8_t* out) {
     if (!c->masks.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no mask for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
-    HIPC(c, hipMemcpyAsync(out, c->masks.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->masks.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, int W) {
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->masks.ensure((size_t)H * W * K));
-    HIPC(c, hipMemcpyAsync(c->masks.p, masks, (size_t)H * W * K, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->masks.p, masks, (size_t)H * W * K, hipMemcpyHostToDevice, LN(c).stream));
     return 0;
 }
 
@@ -560,7 +560,7 @@ extern "C" int orip_keep_layers(orip_ctx* c, const int32_t* layers, int n) {
     size_t plane = (size_t)c->H * c->W;
     for (int i = 0; i < n; i++) {
         if (layers[i] < i || layers[i] >= c->K || (i && layers[i] <= layers[i - 1])) ORIP_FAIL(c, "layer subset must be strictly increasing and within range");
-        if (layers[i] != i) HIPC(c, hipMemcpyAsync(c->masks.as<u8>() + plane * i, c->masks.as<u8>() + plane * layers[i], plane, hipMemcpyDeviceToDevice, c->stream));
+        if (layers[i] != i) HIPC(c, hipMemcpyAsync(c->masks.as<u8>() + plane * i, c->masks.as<u8>() + plane * layers[i], plane, hipMemcpyDeviceToDevice, LN(c).stream));
     }
     c->K = n;
     return 0;

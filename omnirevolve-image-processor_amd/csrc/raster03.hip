@@ -162,10 +162,10 @@ int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value) {
     int H = c->H, W = c->W;
     int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1, pplane = Wb * Hb * 4;
     dim3 grid(cdiv(W, 64), cdiv(H, 4), K), block(256);
-    if ((W & 1) || (H & 1)) HIPC(c, hipMemsetAsync(par, 0xff, (size_t)pplane * K * sizeof(int), c->stream));  // ids of absent pixels
-    { ProfScope ps(c, "k_ccl_init"); hipLaunchKernelGGL(k_ccl_init, grid, block, 0, c->stream, img, par, H, W, bg_value); }
-    { ProfScope ps(c, "k_ccl_merge"); hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, c->stream, img, par, H, W, bg_value); }
-    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_flatten2, dim3(cdiv(pplane, 256), 1, K), block, 0, c->stream, par, pplane); }
+    if ((W & 1) || (H & 1)) HIPC(c, hipMemsetAsync(par, 0xff, (size_t)pplane * K * sizeof(int), LN(c).stream));  // ids of absent pixels
+    { ProfScope ps(c, "k_ccl_init"); hipLaunchKernelGGL(k_ccl_init, grid, block, 0, LN(c).stream, img, par, H, W, bg_value); }
+    { ProfScope ps(c, "k_ccl_merge"); hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, LN(c).stream, img, par, H, W, bg_value); }
+    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_flatten2, dim3(cdiv(pplane, 256), 1, K), block, 0, LN(c).stream, par, pplane); }
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -202,16 +202,16 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
     HIPC(c, c->tmpC.ensure(plane * K));   // NMS map
     ORIP_TRY(orip_morph_open_close(c, c->masks.as<u8>(), c->tmpB.as<u8>(), K, 2, morph_k, open_iters, close_iters, false));
     dim3 grid(cdiv(W, ET_X), cdiv(H, ET_Y), K), block(256);
-    { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, c->stream, c->tmpB.as<u8>(), c->tmpC.as<u8>(), H, W, gauss_k, low, high); }
+    { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), c->tmpC.as<u8>(), H, W, gauss_k, low, high); }
     HIPC(c, hipGetLastError());
     int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; size_t pplane = (size_t)Wb * Hb * 4;
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
-    HIPC(c, c->tmpE.ensure(pplane * K));
+    HIPC(c, LN(c).tmpE.ensure(pplane * K));
     ORIP_TRY(orip_ccl(c, c->tmpC.as<u8>(), c->tmpD.as<int>(), K, 1));
-    HIPC(c, hipMemsetAsync(c->tmpE.p, 0, pplane * K, c->stream));
+    HIPC(c, hipMemsetAsync(LN(c).tmpE.p, 0, pplane * K, LN(c).stream));
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K);
-    { ProfScope ps(c, "k_hyst_mark"); hipLaunchKernelGGL(k_hyst_mark, g2, block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), c->tmpE.as<u8>(), H, W); }
-    { ProfScope ps(c, "k_hyst_out"); hipLaunchKernelGGL(k_hyst_out, g2, block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), c->tmpE.as<u8>(), c->edges.as<u8>(), H, W); }
+    { ProfScope ps(c, "k_hyst_mark"); hipLaunchKernelGGL(k_hyst_mark, g2, block, 0, LN(c).stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), H, W); }
+    { ProfScope ps(c, "k_hyst_out"); hipLaunchKernelGGL(k_hyst_out, g2, block, 0, LN(c).stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), c->edges.as<u8>(), H, W); }
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -219,14 +219,14 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
 extern "C" int orip_get_edges(orip_ctx* c, int layer, uint8_t* out) {
     if (!c->edges.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no edges for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
-    HIPC(c, hipMemcpyAsync(out, c->edges.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->edges.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_set_edges(orip_ctx* c, const uint8_t* edges, int K, int H, int W) {
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->edges.ensure((size_t)H * W * K));
-    HIPC(c, hipMemcpyAsync(c->edges.p, edges, (size_t)H * W * K, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->edges.p, edges, (size_t)H * W * K, hipMemcpyHostToDevice, LN(c).stream));
     return 0;
 }

@@ -161,9 +161,9 @@ __global__ __launch_bounds__(256) void k_expand_cycles(const unsigned long long*
 template <class T>
 static int excl_scan(orip_ctx* c, const T* in, T* out, size_t n, DBuf& tmp) {
     size_t bytes = 0;
-    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), LN(c).stream));
     HIPC(c, tmp.ensure(bytes + 16));
-    HIPC(c, rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    HIPC(c, rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), LN(c).stream));
     return 0;
 }
 
@@ -175,20 +175,20 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     // ---- thinning_zhangsuen (04:35-99): <=120 iterations of two sub-iterations, until nothing is deleted
     HIPC(c, c->skel.ensure(plane * K + 16));
     HIPC(c, c->tmpB.ensure(plane * K + 16));
-    HIPC(c, c->flags.ensure(1024));
-    int* d_changed = c->flags.as<int>() + 8;
+    HIPC(c, LN(c).flags.ensure(1024));
+    int* d_changed = LN(c).flags.as<int>() + 8;
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K), block(256);
     {
         // iteration 1 reads the edges; ping-pong skel <-> tmpB so that the result always lands in skel
         const u8* cur = c->edges.as<u8>();
         for (int it = 0; it < 120; it++) {
-            HIPC(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
-            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, c->stream, cur, c->tmpB.as<u8>(), H, W, 0, d_changed); }
-            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, c->stream, c->tmpB.as<u8>(), c->skel.as<u8>(), H, W, 1, d_changed); }
+            HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
+            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, LN(c).stream, cur, c->tmpB.as<u8>(), H, W, 0, d_changed); }
+            { ProfScope ps(c, "k_thin_sub"); hipLaunchKernelGGL(k_thin_sub, g2, block, 0, LN(c).stream, c->tmpB.as<u8>(), c->skel.as<u8>(), H, W, 1, d_changed); }
             cur = c->skel.as<u8>();
             int h_changed = 0;
-            HIPC(c, hipMemcpyAsync(&h_changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, hipMemcpyAsync(&h_changed, d_changed, 4, hipMemcpyDeviceToHost, LN(c).stream));
+            HIPC(c, hipStreamSynchronize(LN(c).stream));
             if (!h_changed) break;
         }
     }
@@ -197,90 +197,90 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
     ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
     HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
-    { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, c->stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
+    { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     // ---- ordered compaction
     const int nblk = cdiv(n, 1024);
-    HIPC(c, c->tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
-    unsigned* d_cnt = c->tmpE.as<unsigned>(); unsigned* d_boff = d_cnt + nblk + 1;
-    HIPC(c, hipMemsetAsync(d_cnt + nblk, 0, sizeof(unsigned), c->stream));
-    { ProfScope ps(c, "k_compact_count"); hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, c->stream, c->tmpC.as<u8>(), n, d_cnt); }
-    ORIP_TRY(excl_scan<unsigned>(c, d_cnt, d_boff, (size_t)nblk + 1, c->tmpF));
+    HIPC(c, LN(c).tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
+    unsigned* d_cnt = LN(c).tmpE.as<unsigned>(); unsigned* d_boff = d_cnt + nblk + 1;
+    HIPC(c, hipMemsetAsync(d_cnt + nblk, 0, sizeof(unsigned), LN(c).stream));
+    { ProfScope ps(c, "k_compact_count"); hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), n, d_cnt); }
+    ORIP_TRY(excl_scan<unsigned>(c, d_cnt, d_boff, (size_t)nblk + 1, LN(c).tmpF));
     // per-layer fg totals = differences of the scan at layer boundaries (blocks do not align with layers -> count on host from scan + partial)
     unsigned M = 0;
-    HIPC(c, hipMemcpyAsync(&M, d_boff + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(&M, d_boff + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     for (int l = 0; l < K; l++) {
         DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
         P.n = 0; P.total = 0;
-        HIPC(c, P.off.ensure(8)); HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
+        HIPC(c, P.off.ensure(8)); HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
     }
     if (M == 0) return 0;
     // keys / lin (double buffers for the sort)
-    HIPC(c, c->vtmp[0].ensure((size_t)M * 4 * 4 + 64));
-    unsigned* keys_in = c->vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
-    { ProfScope ps(c, "k_compact_write"); hipLaunchKernelGGL(k_compact_write, dim3(nblk), block, 0, c->stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), n, H, W, d_boff, keys_in, lin_in); }
+    HIPC(c, LN(c).vtmp[0].ensure((size_t)M * 4 * 4 + 64));
+    unsigned* keys_in = LN(c).vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
+    { ProfScope ps(c, "k_compact_write"); hipLaunchKernelGGL(k_compact_write, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), n, H, W, d_boff, keys_in, lin_in); }
     {
         size_t bytes = 0;
-        HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, c->stream));
-        HIPC(c, c->tmpF.ensure(bytes + 16));
+        HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, LN(c).stream));
+        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
         ProfScope ps(c, "radix_sort_pairs");
-        HIPC(c, rocprim::radix_sort_pairs(c->tmpF.p, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, c->stream));
+        HIPC(c, rocprim::radix_sort_pairs(LN(c).tmpF.p, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, LN(c).stream));
     }
     // ---- component segmentation
-    HIPC(c, c->vtmp[1].ensure((size_t)M * 2 * 4 + 64));
-    unsigned* head = c->vtmp[1].as<unsigned>(); unsigned* head_scan = head + M;
-    hipLaunchKernelGGL(k_heads, dim3(cdiv(M, 256)), block, 0, c->stream, keys, (int64_t)M, head);
-    ORIP_TRY(excl_scan<unsigned>(c, head, head_scan, (size_t)M, c->tmpF));
+    HIPC(c, LN(c).vtmp[1].ensure((size_t)M * 2 * 4 + 64));
+    unsigned* head = LN(c).vtmp[1].as<unsigned>(); unsigned* head_scan = head + M;
+    hipLaunchKernelGGL(k_heads, dim3(cdiv(M, 256)), block, 0, LN(c).stream, keys, (int64_t)M, head);
+    ORIP_TRY(excl_scan<unsigned>(c, head, head_scan, (size_t)M, LN(c).tmpF));
     unsigned last2[2];
-    HIPC(c, hipMemcpyAsync(&last2[0], head_scan + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(&last2[1], head + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(&last2[0], head_scan + (M - 1), 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipMemcpyAsync(&last2[1], head + (M - 1), 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     const unsigned NC = last2[0] + last2[1];
-    HIPC(c, c->vtmp[2].ensure((size_t)(NC + 2) * 4 + 64));
-    unsigned* comp_start = c->vtmp[2].as<unsigned>();
-    hipLaunchKernelGGL(k_comp_starts, dim3(cdiv(M, 256)), block, 0, c->stream, head, head_scan, (int64_t)M, comp_start, NC);
+    HIPC(c, LN(c).vtmp[2].ensure((size_t)(NC + 2) * 4 + 64));
+    unsigned* comp_start = LN(c).vtmp[2].as<unsigned>();
+    hipLaunchKernelGGL(k_comp_starts, dim3(cdiv(M, 256)), block, 0, LN(c).stream, head, head_scan, (int64_t)M, comp_start, NC);
     // per-layer fg totals and first-component index: binary search on the sorted keys (host side, small readback)
     std::vector<unsigned> h_cs(NC + 1), h_keyfirst(NC);
-    HIPC(c, hipMemcpyAsync(h_cs.data(), comp_start, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(h_cs.data(), comp_start, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     // layer of each component (key of its first element)
-    HIPC(c, c->vtmp[3].ensure((size_t)NC * 4 + 64));
+    HIPC(c, LN(c).vtmp[3].ensure((size_t)NC * 4 + 64));
     WalkArgs A; memset(&A, 0, sizeof(A));
     A.H = H; A.W = W; A.plane = (int64_t)plane; A.st = c->tmpC.as<u8>(); A.keys = keys; A.lin = lin; A.comp_start = comp_start; A.nc = NC;
-    hipLaunchKernelGGL(k_gather_head_layers, dim3(cdiv(NC, 256)), block, 0, c->stream, keys, comp_start, NC, c->vtmp[3].as<unsigned>());
-    HIPC(c, hipMemcpyAsync(h_keyfirst.data(), c->vtmp[3].p, (size_t)NC * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_gather_head_layers, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, keys, comp_start, NC, LN(c).vtmp[3].as<unsigned>());
+    HIPC(c, hipMemcpyAsync(h_keyfirst.data(), LN(c).vtmp[3].p, (size_t)NC * 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     std::vector<unsigned> layer_first(K + 1, NC);
     for (unsigned i = NC; i-- > 0;) layer_first[h_keyfirst[i]] = i;
     for (int l = K - 1; l >= 0; l--) if (layer_first[l] == NC && l + 1 <= K) layer_first[l] = layer_first[l + 1];
     layer_first[K] = NC;
     for (int l = 0; l < K; l++) A.total_fg[l] = (long long)h_cs[layer_first[l + 1]] - (long long)h_cs[layer_first[l]];
     // ---- count pass
-    HIPC(c, c->vtmp[4].ensure((size_t)(NC + 1) * (8 + 8 + 4 + 4) + 256));
-    unsigned long long* comp_pts = c->vtmp[4].as<unsigned long long>(); unsigned long long* pts_base = comp_pts + (NC + 1);
+    HIPC(c, LN(c).vtmp[4].ensure((size_t)(NC + 1) * (8 + 8 + 4 + 4) + 256));
+    unsigned long long* comp_pts = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_base = comp_pts + (NC + 1);
     unsigned* comp_paths = (unsigned*)(pts_base + (NC + 1)); unsigned* path_base = comp_paths + (NC + 1);
-    HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, c->stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, c->stream));
+    HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, LN(c).stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, LN(c).stream));
     A.comp_pts = comp_pts; A.comp_paths = comp_paths; A.pts_base = pts_base; A.path_base = path_base;
     {   // schedule: components by size, descending
-        HIPC(c, c->vtmp[5].ensure((size_t)NC * 16 + 64));
-        unsigned* szin = c->vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
-        hipLaunchKernelGGL(k_comp_sizes, dim3(cdiv(NC, 256)), block, 0, c->stream, comp_start, NC, szin, idin);
+        HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 16 + 64));
+        unsigned* szin = LN(c).vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
+        hipLaunchKernelGGL(k_comp_sizes, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, comp_start, NC, szin, idin);
         size_t bytes = 0;
-        HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, c->stream));
-        HIPC(c, c->tmpF.ensure(bytes + 16));
-        HIPC(c, rocprim::radix_sort_pairs_desc(c->tmpF.p, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, c->stream));
-        HIPC(c, c->vtmp[3].ensure((size_t)NC * 4 + 64));
-        HIPC(c, hipMemcpyAsync(c->vtmp[3].p, idout, (size_t)NC * 4, hipMemcpyDeviceToDevice, c->stream));
-        A.comp_order = c->vtmp[3].as<unsigned>();
+        HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, LN(c).stream));
+        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+        HIPC(c, rocprim::radix_sort_pairs_desc(LN(c).tmpF.p, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, LN(c).stream));
+        HIPC(c, LN(c).vtmp[3].ensure((size_t)NC * 4 + 64));
+        HIPC(c, hipMemcpyAsync(LN(c).vtmp[3].p, idout, (size_t)NC * 4, hipMemcpyDeviceToDevice, LN(c).stream));
+        A.comp_order = LN(c).vtmp[3].as<unsigned>();
     }
-    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(NC), dim3(64), 0, c->stream, A); }
+    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(NC), dim3(64), 0, LN(c).stream, A); }
     HIPC(c, hipGetLastError());
-    ORIP_TRY(excl_scan<unsigned long long>(c, comp_pts, pts_base, (size_t)NC + 1, c->tmpF));
-    ORIP_TRY(excl_scan<unsigned>(c, comp_paths, path_base, (size_t)NC + 1, c->tmpF));
+    ORIP_TRY(excl_scan<unsigned long long>(c, comp_pts, pts_base, (size_t)NC + 1, LN(c).tmpF));
+    ORIP_TRY(excl_scan<unsigned>(c, comp_paths, path_base, (size_t)NC + 1, LN(c).tmpF));
     std::vector<unsigned long long> h_pb(NC + 1); std::vector<unsigned> h_qb(NC + 1);
-    HIPC(c, hipMemcpyAsync(h_pb.data(), pts_base, (size_t)(NC + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(h_qb.data(), path_base, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(h_pb.data(), pts_base, (size_t)(NC + 1) * 8, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipMemcpyAsync(h_qb.data(), path_base, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     for (int l = 0; l < K; l++) {
         DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
         A.layer_pts_base[l] = h_pb[layer_first[l]]; A.layer_path_base[l] = h_qb[layer_first[l]];
@@ -288,26 +288,27 @@ extern "C" int orip_find_contours(orip_ctx* c) {
         P.n = (int64_t)(h_qb[layer_first[l + 1]] - h_qb[layer_first[l]]);
         HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
         HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
-        HIPC(c, hipMemsetAsync(P.off.p, 0, 8, c->stream));
+        HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
         A.pts[l] = P.pts.as<int32_t>(); A.off[l] = P.off.as<int64_t>();
     }
     // ---- write pass
-    hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, c->stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);
+    hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, LN(c).stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);
     // one descriptor per bounce walk; bounded by the number of skeleton pixels
-    HIPC(c, c->vtmp[5].ensure((size_t)M * 32 + 64));
-    A.desc = c->vtmp[5].as<unsigned long long>(); A.desc_cap = M;
-    A.n_desc = (unsigned*)(c->flags.as<int>() + 16);
-    HIPC(c, hipMemsetAsync(A.n_desc, 0, 4, c->stream));
-    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(NC), dim3(64), 0, c->stream, A); }
-    { ProfScope ps(c, "k_expand_cycles"); hipLaunchKernelGGL(k_expand_cycles, dim3(4096), block, 0, c->stream, A.desc, A.n_desc, A); }
+    HIPC(c, LN(c).vtmp[5].ensure((size_t)M * 32 + 64));
+    A.desc = LN(c).vtmp[5].as<unsigned long long>(); A.desc_cap = M;
+    A.n_desc = (unsigned*)(LN(c).flags.as<int>() + 16);
+    HIPC(c, hipMemsetAsync(A.n_desc, 0, 4, LN(c).stream));
+    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(NC), dim3(64), 0, LN(c).stream, A); }
+    { ProfScope ps(c, "k_expand_cycles"); hipLaunchKernelGGL(k_expand_cycles, dim3(4096), block, 0, LN(c).stream, A.desc, A.n_desc, A); }
     HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(LN(c).stream));   // the per-layer stages that follow run on other streams
     return 0;
 }
 
 extern "C" int orip_get_skeleton(orip_ctx* c, int layer, uint8_t* out) {
     if (!c->skel.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no skeleton for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
-    HIPC(c, hipMemcpyAsync(out, c->skel.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(out, c->skel.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }

@@ -12,26 +12,26 @@ template <class T>
 static int vscan_excl(orip_ctx* c, const T* in, T* out, size_t n) {
     if (n == 0) return 0;
     size_t bytes = 0;
-    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
-    HIPC(c, c->tmpF.ensure(bytes + 16));
-    HIPC(c, rocprim::exclusive_scan(c->tmpF.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+    HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), LN(c).stream));
+    HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+    HIPC(c, rocprim::exclusive_scan(LN(c).tmpF.p, bytes, in, out, T(0), n, rocprim::plus<T>(), LN(c).stream));
     return 0;
 }
 template <class K, class V>
 static int vsort_pairs(orip_ctx* c, const K* kin, K* kout, const V* vin, V* vout, size_t n, int begin_bit, int end_bit, bool desc = false) {
     if (n == 0) return 0;
     size_t bytes = 0;
-    if (!desc) HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
-    else HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
-    HIPC(c, c->tmpF.ensure(bytes + 16));
-    if (!desc) HIPC(c, rocprim::radix_sort_pairs(c->tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
-    else HIPC(c, rocprim::radix_sort_pairs_desc(c->tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+    if (!desc) HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, LN(c).stream));
+    else HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, LN(c).stream));
+    HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+    if (!desc) HIPC(c, rocprim::radix_sort_pairs(LN(c).tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, LN(c).stream));
+    else HIPC(c, rocprim::radix_sort_pairs_desc(LN(c).tmpF.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, LN(c).stream));
     return 0;
 }
 template <class T>
 static int vread(orip_ctx* c, T* host, const T* dev, size_t n = 1) {
-    HIPC(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 
@@ -138,15 +138,15 @@ __global__ __launch_bounds__(256) void k_gather_pts(const GatherDesc* __restrict
 static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* src, DPolys& dst) {
     dst.n = n; dst.total = 0;
     HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
-    if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream)); return 0; }
-    HIPC(c, c->tmpE.ensure((size_t)(n + 1) * 8 + 64));
-    hipLaunchKernelGGL(k_gather_lens, dim3(cdiv(n + 1, 256)), dim3(256), 0, c->stream, d, n, c->tmpE.as<int64_t>());
-    ORIP_TRY(vscan_excl<int64_t>(c, c->tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
+    if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
+    HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 8 + 64));
+    hipLaunchKernelGGL(k_gather_lens, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, d, n, LN(c).tmpE.as<int64_t>());
+    ORIP_TRY(vscan_excl<int64_t>(c, LN(c).tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
     int64_t total = 0;
     ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
     dst.total = total;
     HIPC(c, dst.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
-    hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, c->stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>());
+    hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, LN(c).stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>());
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -192,23 +192,23 @@ __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restri
 // Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
 static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int64_t n = src.n;
-    if (n == 0) { dst.n = 0; dst.total = 0; HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream)); return 0; }
+    if (n == 0) { dst.n = 0; dst.total = 0; HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     if (n > 0x7fffffff) ORIP_FAIL(c, "too many polylines");
-    HIPC(c, c->vtmp[6].ensure((size_t)n * (sizeof(PolyFeat) + sizeof(NNEnds) + sizeof(GatherDesc) + 4 + 2) + 256));
-    PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
+    HIPC(c, LN(c).vtmp[6].ensure((size_t)n * (sizeof(PolyFeat) + sizeof(NNEnds) + sizeof(GatherDesc) + 4 + 2) + 256));
+    PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
     NNEnds* ends = (NNEnds*)(feat + n);
     GatherDesc* desc = (GatherDesc*)(ends + n);
     int32_t* order = (int32_t*)(desc + n);
     uint8_t* flips = (uint8_t*)(order + n); uint8_t* used = flips + n;
     int what = kind == 7 ? 4 : (kind == 8 ? 1 : 8);
-    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, c->stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, what, feat);
-    hipLaunchKernelGGL(k_ends_from_feat, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, feat, n, kind == 7 ? 1 : 0, src.off.as<int64_t>(), src.pts.as<int32_t>(), ends);
-    int* d_seed = c->flags.as<int>() + 32;
-    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, c->stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
+    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, what, feat);
+    hipLaunchKernelGGL(k_ends_from_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, src.off.as<int64_t>(), src.pts.as<int32_t>(), ends);
+    int* d_seed = LN(c).flags.as<int>() + 32;
+    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
     int seed = 0;
     ORIP_TRY(vread(c, &seed, d_seed));
-    { ProfScope ps(c, "k_greedy_nn"); hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, c->stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips); }
-    hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
+    { ProfScope ps(c, "k_greedy_nn"); hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips); }
+    hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
     HIPC(c, hipGetLastError());
     return vgather(c, desc, n, src.pts.as<int32_t>(), dst);
 }

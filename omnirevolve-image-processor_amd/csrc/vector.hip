@@ -15,24 +15,29 @@ __global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, 
 
 extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    LaneGuard lane(layer + 1);
     DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
     D.n = S.n; D.total = S.total;
     HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
     HIPC(c, D.pts.ensure((size_t)std::max<int64_t>(S.total, 1) * 8 + 64));
-    if (S.n == 0) { HIPC(c, hipMemsetAsync(D.off.p, 0, 8, c->stream)); return 0; }
-    HIPC(c, hipMemcpyAsync(D.off.p, S.off.p, (size_t)(S.n + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (S.n == 0) { HIPC(c, hipMemsetAsync(D.off.p, 0, 8, LN(c).stream)); return 0; }
+    HIPC(c, hipMemcpyAsync(D.off.p, S.off.p, (size_t)(S.n + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
     if (S.total) {
         ProfScope ps(c, "k_scale_pts");
-        hipLaunchKernelGGL(k_scale_pts, dim3((unsigned)std::min<int64_t>(cdiv(S.total, 256), 8192)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_scale_pts, dim3((unsigned)std::min<int64_t>(cdiv(S.total, 256), 8192)), dim3(256), 0, LN(c).stream,
                            reinterpret_cast<const int2*>(S.pts.p), reinterpret_cast<int2*>(D.pts.p), S.total, sx, sy, dx, dy);
     }
     HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 
 extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
-    return vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7);
+    LaneGuard lane(layer + 1);
+    ORIP_TRY(vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -149,19 +154,20 @@ __global__ __launch_bounds__(1024) void k_plot_order(const PolyFeat* __restrict_
 
 extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t* n_ops) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
+    LaneGuard lane(layer + 1);
     DPolys& L = c->polys[ORIP_SLOT_LINES_CROSS][layer]; DTaps& T = c->taps[ORIP_TAPS_CROSS][layer];
     int64_t nl = L.n, nt = T.n;
     c->n_ops[layer] = 0; *n_ops = 0;
     if (nl + nt == 0) return 0;
     if (nl + nt > 0x3fffffff) ORIP_FAIL(c, "too many ops");
-    HIPC(c, c->vtmp[6].ensure((size_t)std::max<int64_t>(nl, 1) * sizeof(PolyFeat) + (size_t)(nl + nt) + 256));
-    PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
+    HIPC(c, LN(c).vtmp[6].ensure((size_t)std::max<int64_t>(nl, 1) * sizeof(PolyFeat) + (size_t)(nl + nt) + 256));
+    PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
     uint8_t* alive_l = (uint8_t*)(feat + std::max<int64_t>(nl, 1)); uint8_t* alive_t = alive_l + nl;
     HIPC(c, c->ops[layer].ensure((size_t)(nl + nt) * 20 + 64));
     HIPC(c, T.xy.ensure(64));
-    if (nl) hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nl, 128)), dim3(128), 0, c->stream, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, 2, feat);
-    int* d_n = c->flags.as<int>() + 40;
-    { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, c->stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
+    if (nl) hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nl, 128)), dim3(128), 0, LN(c).stream, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, 2, feat);
+    int* d_n = LN(c).flags.as<int>() + 40;
+    { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
     HIPC(c, hipGetLastError());
     int h = 0;
     ORIP_TRY(vread(c, &h, d_n));
@@ -172,8 +178,8 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
 extern "C" int orip_get_ops(orip_ctx* c, int layer, int32_t* ops5) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     if (!c->n_ops[layer]) return 0;
-    HIPC(c, hipMemcpyAsync(ops5, c->ops[layer].p, (size_t)c->n_ops[layer] * 20, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpyAsync(ops5, c->ops[layer].p, (size_t)c->n_ops[layer] * 20, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 

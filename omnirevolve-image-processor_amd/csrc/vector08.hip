@@ -531,24 +531,24 @@ __global__ __launch_bounds__(256) void k_concat_taps(const int2* a, int64_t na, 
 // split_small_and_taps on a DPolys -> kept (opened) + taps appended to tapbuf at tap_base
 int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, DBuf& tapbuf, int64_t tap_base, int64_t* n_taps_out) {
     kept.n = 0; kept.total = 0; *n_taps_out = 0;
-    HIPC(c, kept.off.ensure(64)); HIPC(c, hipMemsetAsync(kept.off.p, 0, 8, c->stream));
+    HIPC(c, kept.off.ensure(64)); HIPC(c, hipMemsetAsync(kept.off.p, 0, 8, LN(c).stream));
     int64_t n = src.n;
     if (n == 0) return 0;
-    HIPC(c, c->vtmp[2].ensure((size_t)(n + 1) * (16 + 8 + 2 * sizeof(GatherDesc)) + 256));
-    unsigned* is_tap = c->vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (n + 1); unsigned* tap_scan = is_keep + (n + 1); unsigned* keep_scan = tap_scan + (n + 1);
+    HIPC(c, LN(c).vtmp[2].ensure((size_t)(n + 1) * (16 + 8 + 2 * sizeof(GatherDesc)) + 256));
+    unsigned* is_tap = LN(c).vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (n + 1); unsigned* tap_scan = is_keep + (n + 1); unsigned* keep_scan = tap_scan + (n + 1);
     int2* tap_xy = (int2*)(keep_scan + (n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (n + 1)); GatherDesc* kd2 = kd + (n + 1);
-    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, c->stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, is_tap, is_keep, tap_xy, kd); }
+    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, is_tap, is_keep, tap_xy, kd); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
     unsigned nt = 0, nk = 0;
     ORIP_TRY(vread(c, &nt, tap_scan + n)); ORIP_TRY(vread(c, &nk, keep_scan + n));
     if (nt) {
-        HIPC(c, tapbuf.ensure((size_t)(tap_base + nt) * 8 + 64, c->stream, true));
-        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, is_tap, tap_scan, n, (const GatherDesc*)nullptr, (GatherDesc*)nullptr, tap_xy, tapbuf.as<int2>() + tap_base);
+        HIPC(c, tapbuf.ensure((size_t)(tap_base + nt) * 8 + 64, LN(c).stream, true));
+        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_tap, tap_scan, n, (const GatherDesc*)nullptr, (GatherDesc*)nullptr, tap_xy, tapbuf.as<int2>() + tap_base);
     }
     *n_taps_out = nt;
     if (nk) {
-        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, is_keep, keep_scan, n, kd, kd2, (const int2*)nullptr, (int2*)nullptr);
+        hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, n, kd, kd2, (const int2*)nullptr, (int2*)nullptr);
         ORIP_TRY(vgather(c, kd2, nk, src.pts.as<int32_t>(), kept));
     }
     HIPC(c, hipGetLastError());
@@ -560,7 +560,6 @@ __global__ __launch_bounds__(256) void k_fill_per(const PolyFeat* __restrict__ f
     if (i < n) { k[i] = f[i].per; v[i] = (unsigned)i; }
 }
 
-struct TmpPolys { DPolys p; ~TmpPolys() { p.off.release(); p.pts.release(); } };
 
 }  // namespace
 
@@ -568,14 +567,16 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (!prm || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
     const orip_params08 P = *prm;
     const int W = P.W, H = P.H;
+    LaneGuard lane(layer + 1);
     if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
     if (!(P.sample_step * 2.0 < P.max_jump)) ORIP_FAIL(c, "dedup_sample_step must be < max_join_jump_px / 2 (stage-A segments are assumed jump-free)");
     DPolys& S = c->polys[ORIP_SLOT_SORTED][layer]; DPolys& OUT = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DTaps& TOUT = c->taps[ORIP_TAPS_INTRA][layer];
     OUT.n = 0; OUT.total = 0; TOUT.n = 0;
-    HIPC(c, OUT.off.ensure(64)); HIPC(c, hipMemsetAsync(OUT.off.p, 0, 8, c->stream));
+    HIPC(c, OUT.off.ensure(64)); HIPC(c, hipMemsetAsync(OUT.off.p, 0, 8, LN(c).stream));
     HIPC(c, TOUT.xy.ensure(64));
     if (S.n == 0) return 0;
-    TmpPolys kept0, cleaned, lines2, merged;
+    struct Ref { DPolys& p; }; Ref kept0{LN(c).tp[0]}, cleaned{LN(c).tp[1]}, lines2{LN(c).tp[2]}, merged{LN(c).tp[3]};
+    for (Ref* r : {&kept0, &cleaned, &lines2, &merged}) { r->p.n = 0; r->p.total = 0; }
     int64_t nt0 = 0, nt2 = 0;
     // ---- A0
     ORIP_TRY(split_small(c, S, P, kept0.p, TOUT.xy, 0, &nt0));
@@ -583,51 +584,51 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (nk > 0) {
         if (kept0.p.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
         // ---- A1: order by perimeter, descending, stable
-        HIPC(c, c->vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
-        PolyFeat* feat = c->vtmp[6].as<PolyFeat>();
-        { ProfScope ps(c, "k_poly_features"); hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, 1, feat); }
-        HIPC(c, c->vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
-        float* kin = c->vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
+        HIPC(c, LN(c).vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
+        PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
+        { ProfScope ps(c, "k_poly_features"); hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, 1, feat); }
+        HIPC(c, LN(c).vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
+        float* kin = LN(c).vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
         unsigned* mr = ord + nk; unsigned* sbase = mr + (nk + 1); RsInfo* info = (RsInfo*)(sbase + (nk + 1) + 2);   // (6 nk + 4) dwords: 8-byte aligned
-        hipLaunchKernelGGL(k_fill_per, dim3(cdiv(nk, 256)), dim3(256), 0, c->stream, feat, nk, kin, vin);
+        hipLaunchKernelGGL(k_fill_per, dim3(cdiv(nk, 256)), dim3(256), 0, LN(c).stream, feat, nk, kin, vin);
         ORIP_TRY((vsort_pairs<float, unsigned>(c, kin, kout, vin, ord, (size_t)nk, 0, 32, true)));
         // ---- A2: resample
-        HIPC(c, c->vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
-        float* cum = c->vtmp[1].as<float>();
+        HIPC(c, LN(c).vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
+        float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
-        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
-        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, c->stream, info, ord, nk, mr);
+        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
+        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
         unsigned MS = 0;
         ORIP_TRY(vread(c, &MS, sbase + nk));
         if (MS > 0) {
             if (MS > 0x7ffffff0u) ORIP_FAIL(c, "too many samples");
-            HIPC(c, c->vtmp[3].ensure((size_t)MS * (8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
-            SampleArrs A; A.sx = c->vtmp[3].as<double>(); A.sy = A.sx + MS; A.xi = (int*)(A.sy + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
+            HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
+            SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.xi = (int*)(A.sy + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
             unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
-            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
+            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
             // ---- A3
-            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3(cdiv(nk, 128)), dim3(128), 0, c->stream, sbase, nk, P.tail_len_px, A, npop, capprev); }
+            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop, capprev); }
             // ---- A4: de-duplicated capsules -> min-sequence canvas
-            HIPC(c, c->canvas.ensure((size_t)W * H * 4 + 64));
-            unsigned* firstseq = c->canvas.as<unsigned>();
-            HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, c->stream));
+            HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
+            unsigned* firstseq = LN(c).canvas.as<unsigned>();
+            HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
             unsigned long long tsize = 1024; while (tsize < 2ull * MS) tsize <<= 1;
-            HIPC(c, c->vtmp[4].ensure((size_t)tsize * 12 + 64));
-            unsigned long long* tkeys = c->vtmp[4].as<unsigned long long>(); unsigned* tvals = (unsigned*)(tkeys + tsize);
-            HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, c->stream));
-            HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, c->stream));
-            { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1); }
-            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, c->stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
+            HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 12 + 64));
+            unsigned long long* tkeys = LN(c).vtmp[4].as<unsigned long long>(); unsigned* tvals = (unsigned*)(tkeys + tsize);
+            HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, LN(c).stream));
+            HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, LN(c).stream));
+            { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1); }
+            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
             // ---- A5: (polyline, cell) buckets in pop order
-            HIPC(c, c->vtmp[5].ensure((size_t)MS * 24 + 64));
-            unsigned long long* ckin = c->vtmp[5].as<unsigned long long>(); unsigned long long* ckout = ckin + MS; unsigned* cvin = (unsigned*)(ckout + MS); unsigned* cvout = cvin + MS;
+            HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
+            unsigned long long* ckin = LN(c).vtmp[5].as<unsigned long long>(); unsigned long long* ckout = ckin + MS; unsigned* cvin = (unsigned*)(ckout + MS); unsigned* cvout = cvin + MS;
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
-            hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, MS, inv, ckin, cvin);
+            hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, MS, inv, ckin, cvin);
             int rbits = 1; while ((1ll << rbits) < nk + 1) rbits++;
             { ProfScope ps(c, "sort_cells"); ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cvin, cvout, (size_t)MS, 0, 32 + rbits))); }
             // ---- A6
-            { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept, dim3(cdiv(MS, 256)), dim3(256), 0, c->stream, A, sbase, npop, MS, inv, P.col_rad * P.col_rad, ckout, cvout, firstseq, W, spt, sflag); }
+            { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, inv, P.col_rad * P.col_rad, ckout, cvout, firstseq, W, spt, sflag); }
             HIPC(c, hipGetLastError());
             ORIP_TRY(orip_runs_to_polys(c, spt, sflag, MS, cleaned.p));
         }
@@ -643,83 +644,85 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         const int Wp = W + 2 * PAD8, Hp = H + 2 * PAD8; const size_t Np = (size_t)Wp * Hp;
         if (Np >= (1ull << 27)) ORIP_FAIL(c, "canvas too large for stage 08-B index packing");
         const int exp = P.post_brush * 2 + 6, rad = std::max(1, P.post_brush) / 2;
-        HIPC(c, c->vtmp[6].ensure((size_t)n2 * sizeof(PolyFeat) + (size_t)(n2 + 1) * (4 + 4 + 4) + (size_t)n2 * sizeof(GroupInfo) + 256));
-        PolyFeat* f2 = c->vtmp[6].as<PolyFeat>(); int* par = (int*)(f2 + n2); unsigned* is_root = (unsigned*)(par + (n2 + 1)); unsigned* root_scan = is_root + (n2 + 1);
+        HIPC(c, LN(c).vtmp[6].ensure((size_t)n2 * sizeof(PolyFeat) + (size_t)(n2 + 1) * (4 + 4 + 4) + (size_t)n2 * sizeof(GroupInfo) + 256));
+        PolyFeat* f2 = LN(c).vtmp[6].as<PolyFeat>(); int* par = (int*)(f2 + n2); unsigned* is_root = (unsigned*)(par + (n2 + 1)); unsigned* root_scan = is_root + (n2 + 1);
         GroupInfo* grp = (GroupInfo*)(root_scan + (n2 + 1) + ((3 * (n2 + 1)) & 1));
-        hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n2, 128)), dim3(128), 0, c->stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, 1, f2);
-        hipLaunchKernelGGL(k_iota, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, par, (int)n2);
-        { ProfScope ps(c, "k_bbox_pairs"); hipLaunchKernelGGL(k_bbox_pairs, dim3((unsigned)std::min<int64_t>(n2, 8192)), dim3(256), 0, c->stream, f2, (int)n2, exp, par); }
-        hipLaunchKernelGGL(k_group_init, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, grp, (int)n2);
-        hipLaunchKernelGGL(k_group_accum, dim3(cdiv(n2 + 1, 256)), dim3(256), 0, c->stream, f2, (int)n2, exp, par, grp, is_root);
+        hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n2, 128)), dim3(128), 0, LN(c).stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, 1, f2);
+        hipLaunchKernelGGL(k_iota, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, par, (int)n2);
+        { ProfScope ps(c, "k_bbox_pairs"); hipLaunchKernelGGL(k_bbox_pairs, dim3((unsigned)std::min<int64_t>(n2, 8192)), dim3(256), 0, LN(c).stream, f2, (int)n2, exp, par); }
+        hipLaunchKernelGGL(k_group_init, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, grp, (int)n2);
+        hipLaunchKernelGGL(k_group_accum, dim3(cdiv(n2 + 1, 256)), dim3(256), 0, LN(c).stream, f2, (int)n2, exp, par, grp, is_root);
         ORIP_TRY(vscan_excl<unsigned>(c, is_root, root_scan, (size_t)n2 + 1));
-        hipLaunchKernelGGL(k_group_finish, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, f2, (int)n2, is_root, root_scan, grp);
+        hipLaunchKernelGGL(k_group_finish, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, f2, (int)n2, is_root, root_scan, grp);
         // raster
-        HIPC(c, c->canvas.ensure(Np * 4 + 64));
-        unsigned* gid = c->canvas.as<unsigned>();
-        HIPC(c, hipMemsetAsync(gid, 0, Np * 4, c->stream));
-        { ProfScope ps(c, "k_stamp_groups"); hipLaunchKernelGGL(k_stamp_groups, dim3(8192), dim3(256), 0, c->stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, par, rad, gid, Wp, Hp); }
-        HIPC(c, c->vtmp[9].ensure(Np * 2 + 64));
-        u8* skA = c->vtmp[9].as<u8>(); u8* skB = skA + Np;
-        hipLaunchKernelGGL(k_gid_to_mask, dim3(cdiv(Np, 256)), dim3(256), 0, c->stream, gid, skA, Np);
-        int* d_changed = c->flags.as<int>() + 48;
+        HIPC(c, LN(c).canvas.ensure(Np * 4 + 64));
+        unsigned* gid = LN(c).canvas.as<unsigned>();
+        HIPC(c, hipMemsetAsync(gid, 0, Np * 4, LN(c).stream));
+        { ProfScope ps(c, "k_stamp_groups"); hipLaunchKernelGGL(k_stamp_groups, dim3(8192), dim3(256), 0, LN(c).stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, par, rad, gid, Wp, Hp); }
+        HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + 64));
+        u8* skA = LN(c).vtmp[9].as<u8>(); u8* skB = skA + Np;
+        hipLaunchKernelGGL(k_gid_to_mask, dim3(cdiv(Np, 256)), dim3(256), 0, LN(c).stream, gid, skA, Np);
+        int* d_changed = LN(c).flags.as<int>() + 48;
         dim3 g2(cdiv(Wp, 64), cdiv(Hp, 4)), blk(256);
         for (int it = 0; it < 48; it++) {
-            HIPC(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
-            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, c->stream, skA, skB, Hp, Wp, 0, d_changed); }
-            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, c->stream, skB, skA, Hp, Wp, 1, d_changed); }
+            HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, LN(c).stream, skA, skB, Hp, Wp, 0, d_changed); }
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, LN(c).stream, skB, skA, Hp, Wp, 1, d_changed); }
             int ch = 0; ORIP_TRY(vread(c, &ch, d_changed));
             if (!ch) break;
         }
         // components
-        HIPC(c, c->vtmp[10].ensure(Np * 4 + 64));
-        int* L2 = c->vtmp[10].as<int>();
-        hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, c->stream, skA, L2, Hp, Wp);
-        { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, c->stream, skA, L2, Hp, Wp); }
-        hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, c->stream, L2, (int)Np);
+        HIPC(c, LN(c).vtmp[10].ensure(Np * 4 + 64));
+        int* L2 = LN(c).vtmp[10].as<int>();
+        hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp);
+        { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp); }
+        hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, L2, (int)Np);
         const int nblk = cdiv((int64_t)Np, 1024);
-        HIPC(c, c->vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
-        unsigned* bc = c->vtmp[0].as<unsigned>(); unsigned* bo = bc + (nblk + 1);
-        HIPC(c, hipMemsetAsync(bc + nblk, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_sk_count, dim3(nblk), blk, 0, c->stream, skA, (int64_t)Np, bc);
+        HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
+        unsigned* bc = LN(c).vtmp[0].as<unsigned>(); unsigned* bo = bc + (nblk + 1);
+        HIPC(c, hipMemsetAsync(bc + nblk, 0, 4, LN(c).stream));
+        hipLaunchKernelGGL(k_sk_count, dim3(nblk), blk, 0, LN(c).stream, skA, (int64_t)Np, bc);
         ORIP_TRY(vscan_excl<unsigned>(c, bc, bo, (size_t)nblk + 1));
         unsigned M = 0; ORIP_TRY(vread(c, &M, bo + nblk));
         if (M > 0) {
-            HIPC(c, c->vtmp[1].ensure((size_t)M * 16 + 64));
-            unsigned* kin = c->vtmp[1].as<unsigned>(); unsigned* lin_in = kin + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
-            hipLaunchKernelGGL(k_sk_write, dim3(nblk), blk, 0, c->stream, skA, L2, (int64_t)Np, bo, kin, lin_in);
+            HIPC(c, LN(c).vtmp[1].ensure((size_t)M * 16 + 64));
+            unsigned* kin = LN(c).vtmp[1].as<unsigned>(); unsigned* lin_in = kin + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
+            hipLaunchKernelGGL(k_sk_write, dim3(nblk), blk, 0, LN(c).stream, skA, L2, (int64_t)Np, bo, kin, lin_in);
             ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, keys, lin_in, lin, (size_t)M, 0, 27)));
-            HIPC(c, c->vtmp[3].ensure((size_t)(M + 1) * 8 + 64));
-            unsigned* head = c->vtmp[3].as<unsigned>(); unsigned* hs = head + (M + 1);
-            hipLaunchKernelGGL(k_heads2, dim3(cdiv(M + 1, 256)), blk, 0, c->stream, keys, (int64_t)M, head);
+            HIPC(c, LN(c).vtmp[3].ensure((size_t)(M + 1) * 8 + 64));
+            unsigned* head = LN(c).vtmp[3].as<unsigned>(); unsigned* hs = head + (M + 1);
+            hipLaunchKernelGGL(k_heads2, dim3(cdiv(M + 1, 256)), blk, 0, LN(c).stream, keys, (int64_t)M, head);
             ORIP_TRY(vscan_excl<unsigned>(c, head, hs, (size_t)M + 1));
             unsigned NC = 0; ORIP_TRY(vread(c, &NC, hs + M));
-            HIPC(c, c->vtmp[4].ensure((size_t)(NC + 1) * (4 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)NC * sizeof(GatherDesc) + 256));
-            unsigned long long* ckin = c->vtmp[4].as<unsigned long long>(); unsigned long long* ckout = ckin + (NC + 1);
+            HIPC(c, LN(c).vtmp[4].ensure((size_t)(NC + 1) * (4 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)NC * sizeof(GatherDesc) + 256));
+            unsigned long long* ckin = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* ckout = ckin + (NC + 1);
             unsigned* cs = (unsigned*)(ckout + (NC + 1)); unsigned* cidx = cs + (NC + 2); unsigned* corder = cidx + (NC + 1); unsigned* outcnt = corder + (NC + 1);
             unsigned* oflag = outcnt + (NC + 1); unsigned* oscan = oflag + (NC + 1); GatherDesc* pd = (GatherDesc*)(oscan + (NC + 1) + ((6 * (NC + 1) + 1) & 1) + 2);
-            hipLaunchKernelGGL(k_comp_starts2, dim3(cdiv(M, 256)), blk, 0, c->stream, head, hs, (int64_t)M, cs, NC);
-            hipLaunchKernelGGL(k_nearest_anchor, dim3(cdiv(M, 256)), blk, 0, c->stream, lin, (int64_t)M, gid, Wp, grp);
-            hipLaunchKernelGGL(k_comp_keys, dim3(cdiv(NC, 128)), dim3(128), 0, c->stream, cs, NC, lin, gid, Wp, grp, ckin, cidx);
+            hipLaunchKernelGGL(k_comp_starts2, dim3(cdiv(M, 256)), blk, 0, LN(c).stream, head, hs, (int64_t)M, cs, NC);
+            hipLaunchKernelGGL(k_nearest_anchor, dim3(cdiv(M, 256)), blk, 0, LN(c).stream, lin, (int64_t)M, gid, Wp, grp);
+            hipLaunchKernelGGL(k_comp_keys, dim3(cdiv(NC, 128)), dim3(128), 0, LN(c).stream, cs, NC, lin, gid, Wp, grp, ckin, cidx);
             ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cidx, corder, (size_t)NC, 0, 64)));
             // per-component path, resample, RDP
-            HIPC(c, c->vtmp[5].ensure(Np * 8 + (size_t)M * (4 + 8 + 8 + 1 + 8) + 256));
-            BfsArrs B; B.sk = skA; B.seen = c->vtmp[5].as<unsigned>(); B.prev = (int*)(B.seen + Np); B.queue = B.prev + Np; B.Wp = Wp; B.Hp = Hp;
+            HIPC(c, LN(c).vtmp[5].ensure(Np * 8 + (size_t)M * (4 + 8 + 8 + 1 + 8) + 256));
+            BfsArrs B; B.sk = skA; B.seen = LN(c).vtmp[5].as<unsigned>(); B.prev = (int*)(B.seen + Np); B.queue = B.prev + Np; B.Wp = Wp; B.Hp = Hp;
             float2* fbuf = (float2*)(B.queue + M + (M & 1)); int2* stk = (int2*)(fbuf + M); int2* outpts = stk + M; uint8_t* keepb = (uint8_t*)(outpts + M);
-            HIPC(c, hipMemsetAsync(B.seen, 0, Np * 4, c->stream));
-            { ProfScope ps(c, "k_comp_paths"); hipLaunchKernelGGL(k_comp_paths, dim3(cdiv(NC, 64)), dim3(64), 0, c->stream, corder, NC, cs, keys, lin, gid, grp, B, P.post_minlen, P.post_step, (float)P.post_eps, fbuf, stk, keepb, outpts, outcnt); }
-            hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, c->stream, outcnt, NC, oflag);
+            HIPC(c, hipMemsetAsync(B.seen, 0, Np * 4, LN(c).stream));
+            { ProfScope ps(c, "k_comp_paths"); hipLaunchKernelGGL(k_comp_paths, dim3(cdiv(NC, 64)), dim3(64), 0, LN(c).stream, corder, NC, cs, keys, lin, gid, grp, B, P.post_minlen, P.post_step, (float)P.post_eps, fbuf, stk, keepb, outpts, outcnt); }
+            hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, LN(c).stream, outcnt, NC, oflag);
             ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
             unsigned NP = 0; ORIP_TRY(vread(c, &NP, oscan + NC));
             merged.p.n = 0; merged.p.total = 0;
-            HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, c->stream));
+            HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream));
             if (NP) {
-                hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, c->stream, corder, cs, outcnt, oflag, oscan, NC, pd);
+                hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, cs, outcnt, oflag, oscan, NC, pd);
                 ORIP_TRY(vgather(c, pd, NP, reinterpret_cast<const int32_t*>(outpts), merged.p));
             }
-        } else { merged.p.n = 0; merged.p.total = 0; HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, c->stream)); }
+        } else { merged.p.n = 0; merged.p.total = 0; HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream)); }
         HIPC(c, hipGetLastError());
         fin = &merged.p;
     }
     // ---- C
-    return vreorder(c, *fin, OUT, 8);
+    ORIP_TRY(vreorder(c, *fin, OUT, 8));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    return 0;
 }

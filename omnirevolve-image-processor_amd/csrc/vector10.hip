@@ -93,28 +93,28 @@ __global__ __launch_bounds__(256) void k_run_desc(const unsigned* __restrict__ r
 // Shared by stage 08-A and stage 10: turn per-slot flags (bit0 accepted, bit1 sequence start) + points into a DPolys of runs with >= 2 points
 int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst) {
     dst.n = 0; dst.total = 0;
-    HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, c->stream));
+    HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream));
     if (n_slots == 0) return 0;
-    HIPC(c, c->vtmp[7].ensure((size_t)n_slots * 8 + 64));
-    unsigned* start = c->vtmp[7].as<unsigned>(); unsigned* start_scan = start + n_slots;
-    hipLaunchKernelGGL(k_run_starts, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, sflag, n_slots, start);
+    HIPC(c, LN(c).vtmp[7].ensure((size_t)n_slots * 8 + 64));
+    unsigned* start = LN(c).vtmp[7].as<unsigned>(); unsigned* start_scan = start + n_slots;
+    hipLaunchKernelGGL(k_run_starts, dim3(cdiv(n_slots, 256)), dim3(256), 0, LN(c).stream, sflag, n_slots, start);
     ORIP_TRY(vscan_excl<unsigned>(c, start, start_scan, n_slots));
     unsigned a[2];
     ORIP_TRY(vread(c, &a[0], start_scan + (n_slots - 1)));
     ORIP_TRY(vread(c, &a[1], start + (n_slots - 1)));
     unsigned n_runs = a[0] + a[1];
     if (n_runs == 0) return 0;
-    HIPC(c, c->vtmp[8].ensure((size_t)(n_runs + 1) * 16 + (size_t)n_runs * sizeof(GatherDesc) + 256));
-    unsigned* rlen = c->vtmp[8].as<unsigned>(); unsigned* rbegin = rlen + (n_runs + 1); unsigned* keep = rbegin + (n_runs + 1); unsigned* keep_scan = keep + (n_runs + 1);
+    HIPC(c, LN(c).vtmp[8].ensure((size_t)(n_runs + 1) * 16 + (size_t)n_runs * sizeof(GatherDesc) + 256));
+    unsigned* rlen = LN(c).vtmp[8].as<unsigned>(); unsigned* rbegin = rlen + (n_runs + 1); unsigned* keep = rbegin + (n_runs + 1); unsigned* keep_scan = keep + (n_runs + 1);
     GatherDesc* desc = (GatherDesc*)(keep_scan + (n_runs + 1) + 2);
-    HIPC(c, hipMemsetAsync(rlen, 0, (size_t)(n_runs + 1) * 4, c->stream));
-    hipLaunchKernelGGL(k_run_accum, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, sflag, start, start_scan, n_slots, rlen, rbegin);
-    hipLaunchKernelGGL(k_run_keep, dim3(cdiv(n_runs + 1, 256)), dim3(256), 0, c->stream, rlen, n_runs, 2u, keep);
+    HIPC(c, hipMemsetAsync(rlen, 0, (size_t)(n_runs + 1) * 4, LN(c).stream));
+    hipLaunchKernelGGL(k_run_accum, dim3(cdiv(n_slots, 256)), dim3(256), 0, LN(c).stream, sflag, start, start_scan, n_slots, rlen, rbegin);
+    hipLaunchKernelGGL(k_run_keep, dim3(cdiv(n_runs + 1, 256)), dim3(256), 0, LN(c).stream, rlen, n_runs, 2u, keep);
     ORIP_TRY(vscan_excl<unsigned>(c, keep, keep_scan, (size_t)n_runs + 1));
     unsigned n_keep = 0;
     ORIP_TRY(vread(c, &n_keep, keep_scan + n_runs));
     if (n_keep == 0) return 0;
-    hipLaunchKernelGGL(k_run_desc, dim3(cdiv(n_runs, 256)), dim3(256), 0, c->stream, rlen, rbegin, keep, keep_scan, n_runs, desc);
+    hipLaunchKernelGGL(k_run_desc, dim3(cdiv(n_runs, 256)), dim3(256), 0, LN(c).stream, rlen, rbegin, keep, keep_scan, n_runs, desc);
     HIPC(c, hipGetLastError());
     return vgather(c, desc, n_keep, reinterpret_cast<const int32_t*>(spt), dst);
 }
@@ -248,87 +248,85 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
     const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
     const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));
     if (rad_lines > ORIP_PAD - 2 || rad_taps > 200) ORIP_FAIL(c, "brush radius %d/%d too large for the padded raster", rad_lines, rad_taps);
-    HIPC(c, c->canvas.ensure((size_t)W * H + 64));
-    u8* forb = c->canvas.as<u8>();
-    HIPC(c, hipMemsetAsync(forb, 0, (size_t)W * H, c->stream));
-    HIPC(c, c->vtmp[9].ensure((size_t)Wp * Hp * 2 + 64));
-    u8* seeds = c->vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp;
+    HIPC(c, LN(c).canvas.ensure((size_t)W * H + 64));
+    u8* forb = LN(c).canvas.as<u8>();
+    HIPC(c, hipMemsetAsync(forb, 0, (size_t)W * H, LN(c).stream));
+    HIPC(c, LN(c).vtmp[9].ensure((size_t)Wp * Hp * 2 + 64));
+    u8* seeds = LN(c).vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp;
     for (int li = 0; li < n_layers; li++) {
         const int layer = order[li];
         if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
         DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
         DTaps& Tin = c->taps[ORIP_TAPS_INTRA][layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
         // ---- 1) cut
-        DPolys cut;   // temporaries owned by this call
-        struct Guard { DPolys* a; DPolys* b; ~Guard() { a->off.release(); a->pts.release(); b->off.release(); b->pts.release(); } };
-        DPolys keepl; Guard guard{&cut, &keepl};
+        DPolys& cut = LN(c).tp[4]; DPolys& keepl = LN(c).tp[5];   // persistent temporaries of this lane
         cut.n = 0; cut.total = 0;
         if (Lin.n > 0 && Lin.total > 0) {
             if (Lin.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
-            HIPC(c, c->vtmp[0].ensure((size_t)(Lin.total + 1) * 9 + 64));
-            unsigned* cnt = c->vtmp[0].as<unsigned>(); unsigned* base = cnt + (Lin.total + 1); uint8_t* fop = (uint8_t*)(base + (Lin.total + 1));
-            HIPC(c, hipMemsetAsync(cnt + Lin.total, 0, 4, c->stream));
-            hipLaunchKernelGGL(k_cut_counts, dim3((unsigned)std::min<int64_t>(Lin.n, 65535)), dim3(256), 0, c->stream, Lin.off.as<int64_t>(), Lin.pts.as<int32_t>(), Lin.n, P.step_px, cnt, fop);
+            HIPC(c, LN(c).vtmp[0].ensure((size_t)(Lin.total + 1) * 9 + 64));
+            unsigned* cnt = LN(c).vtmp[0].as<unsigned>(); unsigned* base = cnt + (Lin.total + 1); uint8_t* fop = (uint8_t*)(base + (Lin.total + 1));
+            HIPC(c, hipMemsetAsync(cnt + Lin.total, 0, 4, LN(c).stream));
+            hipLaunchKernelGGL(k_cut_counts, dim3((unsigned)std::min<int64_t>(Lin.n, 65535)), dim3(256), 0, LN(c).stream, Lin.off.as<int64_t>(), Lin.pts.as<int32_t>(), Lin.n, P.step_px, cnt, fop);
             ORIP_TRY(vscan_excl<unsigned>(c, cnt, base, (size_t)Lin.total + 1));
             unsigned n_slots = 0;
             ORIP_TRY(vread(c, &n_slots, base + Lin.total));
             if (n_slots) {
-                HIPC(c, c->vtmp[1].ensure((size_t)n_slots * 9 + 64));
-                int2* spt = c->vtmp[1].as<int2>(); uint8_t* sflag = (uint8_t*)(spt + n_slots);
-                { ProfScope ps(c, "k_cut_slots"); hipLaunchKernelGGL(k_cut_slots, dim3(cdiv(n_slots, 256)), dim3(256), 0, c->stream, Lin.pts.as<int32_t>(), cnt, base, Lin.total, fop, n_slots, forb, H, W, spt, sflag); }
+                HIPC(c, LN(c).vtmp[1].ensure((size_t)n_slots * 9 + 64));
+                int2* spt = LN(c).vtmp[1].as<int2>(); uint8_t* sflag = (uint8_t*)(spt + n_slots);
+                { ProfScope ps(c, "k_cut_slots"); hipLaunchKernelGGL(k_cut_slots, dim3(cdiv(n_slots, 256)), dim3(256), 0, LN(c).stream, Lin.pts.as<int32_t>(), cnt, base, Lin.total, fop, n_slots, forb, H, W, spt, sflag); }
                 ORIP_TRY(orip_runs_to_polys(c, spt, sflag, n_slots, cut));
             }
         }
         // ---- 2,3) jumps are the identity; tiny lines -> taps / dropped
         int64_t n_tap_lines = 0;
         keepl.n = 0; keepl.total = 0;
-        HIPC(c, c->vtmp[2].ensure((size_t)(cut.n + 1) * (16 + 8 + sizeof(GatherDesc)) + 256));
-        unsigned* is_tap = c->vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (cut.n + 1); unsigned* tap_scan = is_keep + (cut.n + 1); unsigned* keep_scan = tap_scan + (cut.n + 1);
+        HIPC(c, LN(c).vtmp[2].ensure((size_t)(cut.n + 1) * (16 + 8 + sizeof(GatherDesc)) + 256));
+        unsigned* is_tap = LN(c).vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (cut.n + 1); unsigned* tap_scan = is_keep + (cut.n + 1); unsigned* keep_scan = tap_scan + (cut.n + 1);
         int2* tap_xy = (int2*)(keep_scan + (cut.n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (cut.n + 1));
         int64_t n_seq = Tin.n;
         if (cut.n > 0) {
-            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, c->stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, is_tap, is_keep, tap_xy);
+            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, is_tap, is_keep, tap_xy);
             ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
             ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));
             unsigned a = 0, b = 0;
             ORIP_TRY(vread(c, &a, tap_scan + cut.n)); ORIP_TRY(vread(c, &b, keep_scan + cut.n));
             n_tap_lines = a;
             if (b) {
-                hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, c->stream, is_keep, keep_scan, cut.n, cut.off.as<int64_t>(), kd, (const int2*)nullptr, (int2*)nullptr);
+                hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, cut.n, cut.off.as<int64_t>(), kd, (const int2*)nullptr, (int2*)nullptr);
                 ORIP_TRY(vgather(c, kd, b, cut.pts.as<int32_t>(), keepl));
             }
         }
         // taps_seq = taps_in + taps_from_lines
         n_seq = Tin.n + n_tap_lines;
-        HIPC(c, c->vtmp[3].ensure((size_t)(n_seq + 1) * 16 + 64));
-        int2* seq = c->vtmp[3].as<int2>(); int2* acc = seq + (n_seq + 1);
-        if (Tin.n) HIPC(c, hipMemcpyAsync(seq, Tin.xy.p, (size_t)Tin.n * 8, hipMemcpyDeviceToDevice, c->stream));
-        if (n_tap_lines) hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, c->stream, is_tap, tap_scan, cut.n, cut.off.as<int64_t>(), (GatherDesc*)nullptr, tap_xy, seq + Tin.n);
+        HIPC(c, LN(c).vtmp[3].ensure((size_t)(n_seq + 1) * 16 + 64));
+        int2* seq = LN(c).vtmp[3].as<int2>(); int2* acc = seq + (n_seq + 1);
+        if (Tin.n) HIPC(c, hipMemcpyAsync(seq, Tin.xy.p, (size_t)Tin.n * 8, hipMemcpyDeviceToDevice, LN(c).stream));
+        if (n_tap_lines) hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, LN(c).stream, is_tap, tap_scan, cut.n, cut.off.as<int64_t>(), (GatherDesc*)nullptr, tap_xy, seq + Tin.n);
         // ---- 4) reorder
         ORIP_TRY(vreorder(c, keepl, Lout, 10));
         // ---- 5) paint lines (exact disc dilation of all vertices)
         if (Lout.total > 0) {
-            HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, c->stream));
-            hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, c->stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp);
-            { ProfScope ps(c, "k_row_hdist"); hipLaunchKernelGGL(k_row_hdist, dim3(Hp), dim3(64), 0, c->stream, seeds, hd, Hp, Wp); }
-            { ProfScope ps(c, "k_col_cover"); hipLaunchKernelGGL(k_col_cover, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), 0, c->stream, hd, forb, H, W, Hp, Wp, rad_lines); }
+            HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, LN(c).stream));
+            hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp);
+            { ProfScope ps(c, "k_row_hdist"); hipLaunchKernelGGL(k_row_hdist, dim3(Hp), dim3(64), 0, LN(c).stream, seeds, hd, Hp, Wp); }
+            { ProfScope ps(c, "k_col_cover"); hipLaunchKernelGGL(k_col_cover, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), 0, LN(c).stream, hd, forb, H, W, Hp, Wp, rad_lines); }
         }
         // ---- 6) sequential taps
         Tout.n = 0;
         HIPC(c, Tout.xy.ensure((size_t)std::max<int64_t>(n_seq, 1) * 8 + 64));
         if (n_seq > 0) {
-            int* d_n = c->flags.as<int>() + 44;
-            { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, c->stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
+            int* d_n = LN(c).flags.as<int>() + 44;
+            { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
             int na = 0;
             ORIP_TRY(vread(c, &na, d_n));
             Tout.n = na;
             if (na) {
-                HIPC(c, hipMemcpyAsync(Tout.xy.p, acc, (size_t)na * 8, hipMemcpyDeviceToDevice, c->stream));
-                hipLaunchKernelGGL(k_stamp_discs, dim3((unsigned)std::min(na, 4096)), dim3(256), 0, c->stream, acc, na, rad_taps, forb, H, W);
+                HIPC(c, hipMemcpyAsync(Tout.xy.p, acc, (size_t)na * 8, hipMemcpyDeviceToDevice, LN(c).stream));
+                hipLaunchKernelGGL(k_stamp_discs, dim3((unsigned)std::min(na, 4096)), dim3(256), 0, LN(c).stream, acc, na, rad_taps, forb, H, W);
             }
         }
         HIPC(c, hipGetLastError());
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipStreamSynchronize(LN(c).stream));
     }
     return 0;
 }

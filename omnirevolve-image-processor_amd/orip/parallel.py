@@ -102,10 +102,11 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
         dev.find_contours()
         sx, sy, dx, dy = scale_factors(cfg, W, H)
         p8 = S.params08(cfg)
-        for l in mine_local:
+        def per_layer(l):
             dev.scale_vectors(l, sx, sy, dx, dy)
             dev.sort_contours(l)
             dev.dedup_layer(l, p8)
+        S.for_each_layer(per_layer, mine_local)
     if world > 1:
         local = {g: (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i)) for i, g in enumerate(mine)}
         allv = exchange_layer_lists(local, K, coll_device)
@@ -116,7 +117,4 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
     order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
     dev.dedup_cross(order, S.params10(cfg))
     R = S.r_insert12(cfg)
-    n_ops = 0
-    for g in (mine if world > 1 else range(K)):
-        n_ops += len(dev.plot_order(g, R))
-    return n_ops
+    return sum(len(o) for o in S.for_each_layer(lambda g: dev.plot_order(g, R), mine if world > 1 else range(K)))

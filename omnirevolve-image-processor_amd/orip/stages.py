@@ -183,6 +183,24 @@ def plot_order(lines: Sequence[np.ndarray], taps: Sequence[Tuple[int, int]], cfg
     return ops_from_device(d, layer, r_insert12(cfg))
 
 
+# ---------------------------------------------------------------- layer concurrency
+_pool = None
+
+
+def for_each_layer(fn, layers):
+    """Run fn(layer) for every layer from its own host thread.  The per-layer entry points of liborip.so (05, 07, 08, 12)
+    use one HIP stream and one scratch set per layer and ctypes drops the GIL during the call, so the latency-bound
+    kernels of different layers overlap on the GPU (the reference loops over layers serially: 05:114, 07:99, 08:561, 12:200)."""
+    global _pool
+    layers = list(layers)
+    if len(layers) <= 1:
+        return [fn(l) for l in layers]
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=_l.MAX_LAYERS)
+    return list(_pool.map(fn, layers))
+
+
 # ---------------------------------------------------------------- the resident end-to-end path
 def run_path(bgr: np.ndarray, cfg: Config, dev: Device | None = None, centers: np.ndarray | None = None, upto: int = 12,
              fetch_ops: bool = True):
@@ -203,22 +221,21 @@ def run_path(bgr: np.ndarray, cfg: Config, dev: Device | None = None, centers: n
     d.find_contours()
     if upto < 5: return None
     sx, sy, dx, dy = scale_factors(cfg, W, H)
-    for l in range(K):
-        d.scale_vectors(l, sx, sy, dx, dy)
-    if upto < 7: return None
-    for l in range(K):
-        d.sort_contours(l)
-    if upto < 8: return None
     p8 = params08(cfg)
-    for l in range(K):
-        d.dedup_layer(l, p8)
+
+    def per_layer(l):          # stages 05, 07, 08 of one layer; each layer runs on its own HIP stream (lane l+1 of the context)
+        d.scale_vectors(l, sx, sy, dx, dy)
+        if upto >= 7: d.sort_contours(l)
+        if upto >= 8: d.dedup_layer(l, p8)
+
+    for_each_layer(per_layer, range(K))
     if upto < 10: return None
     order = sorted(range(K), key=lambda l: (darkness_rank10(lnames[l]), names.index(lnames[l])))
     d.dedup_cross(order, params10(cfg))
     if upto < 12: return None
     R = r_insert12(cfg)
     if not fetch_ops:
-        for l in range(K):
-            d.plot_order(l, R)
+        for_each_layer(lambda l: d.plot_order(l, R), range(K))
         return None
-    return {lnames[l]: ops_from_device(d, l, R) for l in range(K)}
+    res = for_each_layer(lambda l: ops_from_device(d, l, R), range(K))
+    return {lnames[l]: res[i] for i, l in enumerate(range(K))}
