@@ -45,6 +45,7 @@ struct PolyFeat {
     uint8_t closed;             // first == last on the ORIGINAL polyline (n >= 2)
 };
 
+#define ORIP_LONG_POLY 2048
 // what: bit0 perimeter KIND0, bit1 perimeter KIND1 (hypot), bit2 arcLength closed, bit3 arcLength open, bit4 open view (_ensure_open)
 __global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
                                                         PolyFeat* __restrict__ out) {
@@ -56,16 +57,94 @@ __global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict
     f.closed = (n >= 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) ? 1 : 0;
     if ((what & 16) && f.closed) n -= 1;
     f.n = n;
+    f.sx = p[0]; f.sy = p[1]; f.ex = p[2 * (n - 1)]; f.ey = p[2 * (n - 1) + 1];
+    f.per = 0.f; f.arc = 0.0; f.x0 = f.x1 = p[0]; f.y0 = f.y1 = p[1];
+    if (n > ORIP_LONG_POLY) { out[i] = f; return; }      // bbox / sums of long polylines: k_poly_features_long (one block each)
     int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
     for (int64_t k = 1; k < n; k++) { int32_t x = p[2 * k], y = p[2 * k + 1]; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
-    f.sx = p[0]; f.sy = p[1]; f.ex = p[2 * (n - 1)]; f.ey = p[2 * (n - 1) + 1];
-    f.per = 0.f; f.arc = 0.0;
     if (what & 1) f.per = vs::pairwise_seglen_sum<0>(p, n);
     if (what & 2) f.per = vs::pairwise_seglen_sum<1>(p, n);
     if (what & 4) f.arc = vs::arc_length(p, n, true);
     if (what & 8) f.arc = vs::arc_length(p, n, false);
     out[i] = f;
+}
+
+
+// Long polylines (n > ORIP_LONG_POLY): one 256-thread block per polyline.  bbox and cv::arcLength are plain parallel
+// reductions (the double sum of float edge lengths is exact at these magnitudes, so its order is free).  The numpy float32
+// pairwise perimeter keeps numpy's exact tree: every leaf of the tree has 64..128 elements (n2 = n/2 - (n/2)%8 >= 64 for
+// n > 128), so each multiple of 64 lies in exactly one leaf; the thread that holds the first multiple of 64 of a leaf sums
+// that leaf in numpy's 8-accumulator order, and thread 0 then combines the leaf sums with the explicit-stack traversal.
+template <int KIND>
+__device__ float pairwise_long_combine(const float* __restrict__ leafsum, int64_t n) {
+    int64_t fs[48], fn[48]; int fstate[48]; float fleft[48];
+    int sp = 1; fs[0] = 0; fn[0] = n; fstate[0] = 0;
+    float ret = 0.f;
+    while (sp > 0) {
+        int t = sp - 1;
+        if (fn[t] <= 128) { ret = leafsum[(fs[t] + 63) >> 6]; sp--; continue; }
+        int64_t n2 = fn[t] / 2; n2 -= n2 % 8;
+        if (fstate[t] == 0) { fstate[t] = 1; fs[sp] = fs[t]; fn[sp] = n2; fstate[sp] = 0; sp++; }
+        else if (fstate[t] == 1) { fleft[t] = ret; fstate[t] = 2; fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fstate[sp] = 0; sp++; }
+        else { ret = fleft[t] + ret; sp--; }
+    }
+    return ret;
+}
+__global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
+                                                             PolyFeat* __restrict__ out, float* __restrict__ leafbuf) {
+    __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
+    __shared__ double rarc[256];
+    for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
+        PolyFeat f = out[i];
+        const int64_t n = f.n;                     // already the open view when requested
+        if (n <= ORIP_LONG_POLY) continue;         // uniform for the block
+        const int32_t* p = pts + 2 * off[i];
+        const int tid = threadIdx.x;
+        int x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1]; double arc = 0.0;
+        const bool closed_arc = (what & 4) != 0, any_arc = (what & 12) != 0;
+        for (int64_t k = tid; k < n; k += 256) {
+            int x = p[2 * k], y = p[2 * k + 1];
+            x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+            if (any_arc) {
+                int64_t pk = k == 0 ? (closed_arc ? n - 1 : 0) : k - 1;
+                float dx = (float)x - (float)p[2 * pk], dy = (float)y - (float)p[2 * pk + 1];
+                arc += (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            }
+        }
+        rx0[tid] = x0; rx1[tid] = x1; ry0[tid] = y0; ry1[tid] = y1; rarc[tid] = arc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) { rx0[tid] = min(rx0[tid], rx0[tid + s]); rx1[tid] = max(rx1[tid], rx1[tid + s]); ry0[tid] = min(ry0[tid], ry0[tid + s]); ry1[tid] = max(ry1[tid], ry1[tid + s]); rarc[tid] += rarc[tid + s]; }
+            __syncthreads();
+        }
+        float per = 0.f;
+        if (what & 3) {
+            const int64_t ns = n - 1;               // number of segments
+            float* ls = leafbuf + (off[i] >> 6) + 2 * i;
+            for (int64_t pm = (int64_t)tid * 64; pm < ns; pm += 256 * 64) {
+                int64_t s = 0, len = ns;
+                while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
+                if (((s + 63) >> 6) << 6 == pm) ls[pm >> 6] = (what & 1) ? vs::pairwise_leaf<0>(p, s, len) : vs::pairwise_leaf<1>(p, s, len);
+            }
+            __syncthreads();
+            if (tid == 0) per = (what & 1) ? pairwise_long_combine<0>(ls, ns) : pairwise_long_combine<1>(ls, ns);
+        }
+        if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; }
+        __syncthreads();
+    }
+}
+// features of every polyline of a list: short ones one lane each, long ones one block each
+static int vfeatures(orip_ctx* c, const int64_t* off, const int32_t* pts, int64_t n, int64_t total, int what, PolyFeat* feat) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, off, pts, n, what, feat);
+    if (total > ORIP_LONG_POLY) {
+        HIPC(c, LN(c).vtmp[11].ensure(((size_t)(total >> 6) + 2 * (size_t)n + 8) * sizeof(float)));
+        ProfScope ps(c, "k_poly_features_long");
+        hipLaunchKernelGGL(k_poly_features_long, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, off, pts, n, what, feat, LN(c).vtmp[11].as<float>());
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
 }
 
 // ---- greedy nearest-neighbour ordering (07:55-79 / 08:223-248 / 10:69-97), one 1024-thread block per list ----
@@ -116,6 +195,64 @@ __global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ e
         }
         __syncthreads();
     }
+}
+
+// LDS-resident variant: end points as int16 quads + a state byte per polyline live in LDS (n <= 16000), so a greedy step costs
+// two barriers and a few LDS reads instead of global-memory round trips.  Same selection rule, same tie-break.
+__global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict__ ends, int n, int seed, int rule07,
+                                                         int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    short4* P = reinterpret_cast<short4*>(smem);                 // (sx, sy, ex, ey)
+    uint8_t* stt = smem + (size_t)n * sizeof(short4);            // bit0 used, bit1 closed
+    __shared__ unsigned long long wbest[16];
+    __shared__ int cxs, cys;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) {
+        NNEnds e = ends[i];
+        P[i] = make_short4((short)e.sx, (short)e.sy, (short)e.ex, (short)e.ey);
+        stt[i] = (uint8_t)((i == seed ? 1 : 0) | ((rule07 && e.closed) ? 2 : 0));
+    }
+    if (tid == 0) {
+        order[0] = seed; flips[0] = 0;
+        NNEnds e = ends[seed];
+        if (rule07 && e.closed) { cxs = e.sx; cys = e.sy; } else { cxs = e.ex; cys = e.ey; }
+    }
+    __syncthreads();
+    for (int step = 1; step < n; step++) {
+        const int cx = cxs, cy = cys;
+        unsigned long long best = ~0ULL;
+        for (int i = tid; i < n; i += 1024) {
+            uint8_t f = stt[i];
+            if (f & 1) continue;
+            short4 e = P[i];
+            float ds = nn_d2(e.x, e.y, cx, cy);
+            float v = ds;
+            if (!(f & 2)) { float de = nn_d2(e.z, e.w, cx, cy); if (!(ds <= de)) v = de; }
+            unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
+            if (key < best) best = key;
+        }
+        for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(best, o, 64); if (t < best) best = t; }
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = wbest[0];
+            for (int w = 1; w < 16; w++) if (wbest[w] < b) b = wbest[w];
+            int bi = (int)(b & 0xffffffffu);
+            short4 e = P[bi]; uint8_t f = stt[bi];
+            float ds = nn_d2(e.x, e.y, cx, cy), de = nn_d2(e.z, e.w, cx, cy);
+            bool cl = (f & 2) != 0;
+            bool flip = cl ? false : !(ds <= de);
+            stt[bi] = f | 1; order[step] = bi; flips[step] = flip ? 1 : 0;
+            if (cl || flip) { cxs = e.x; cys = e.y; } else { cxs = e.z; cys = e.w; }
+        }
+        __syncthreads();
+    }
+}
+// 1 if every coordinate fits int16 (the LDS variant is then exact)
+__global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
+    int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+    NNEnds q = e[i];
+    if (q.sx < -32768 || q.sx > 32767 || q.sy < -32768 || q.sy > 32767 || q.ex < -32768 || q.ex > 32767 || q.ey < -32768 || q.ey > 32767) *bad = 1;
 }
 
 // ---- descriptor-driven gather: output polyline k = src points [begin[k], begin[k]+len[k]) (reversed if rev[k]) ----
@@ -201,13 +338,25 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int32_t* order = (int32_t*)(desc + n);
     uint8_t* flips = (uint8_t*)(order + n); uint8_t* used = flips + n;
     int what = kind == 7 ? 4 : (kind == 8 ? 1 : 8);
-    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, what, feat);
+    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, what, feat));
     hipLaunchKernelGGL(k_ends_from_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, src.off.as<int64_t>(), src.pts.as<int32_t>(), ends);
     int* d_seed = LN(c).flags.as<int>() + 32;
+    HIPC(c, hipMemsetAsync(d_seed + 1, 0, 4, LN(c).stream));
     hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
-    int seed = 0;
-    ORIP_TRY(vread(c, &seed, d_seed));
-    { ProfScope ps(c, "k_greedy_nn"); hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips); }
+    hipLaunchKernelGGL(k_ends_fit16, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, ends, (int)n, d_seed + 1);
+    int hs[2] = {0, 0};
+    ORIP_TRY(vread(c, hs, d_seed, 2));
+    const int seed = hs[0];
+    const size_t lds = (size_t)n * 9 + 16;
+    if (n <= 16000 && !hs[1]) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        ProfScope ps(c, "k_greedy_nn");
+        hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, order, flips);
+    } else {
+        ProfScope ps(c, "k_greedy_nn");
+        hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips);
+    }
     hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
     HIPC(c, hipGetLastError());
     return vgather(c, desc, n, src.pts.as<int32_t>(), dst);

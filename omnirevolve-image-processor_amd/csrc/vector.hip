@@ -165,7 +165,7 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
     uint8_t* alive_l = (uint8_t*)(feat + std::max<int64_t>(nl, 1)); uint8_t* alive_t = alive_l + nl;
     HIPC(c, c->ops[layer].ensure((size_t)(nl + nt) * 20 + 64));
     HIPC(c, T.xy.ensure(64));
-    if (nl) hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nl, 128)), dim3(128), 0, LN(c).stream, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, 2, feat);
+    if (nl) ORIP_TRY(vfeatures(c, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, L.total, 2, feat));
     int* d_n = LN(c).flags.as<int>() + 40;
     { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
     HIPC(c, hipGetLastError());

@@ -17,7 +17,7 @@ int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsig
 namespace {
 
 // ================================================================= A0 / A7: _split_small_and_taps (08:198-216)
-__global__ __launch_bounds__(128) void k_split_small08(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params08 P,
+__global__ __launch_bounds__(128) void k_split_small08(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params08 P, const PolyFeat* __restrict__ feat,
                                                         unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy, GatherDesc* __restrict__ kd) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_polys) return;
@@ -26,8 +26,7 @@ __global__ __launch_bounds__(128) void k_split_small08(const int64_t* __restrict
     unsigned tap = 0, keep = 0;
     GatherDesc g; g.begin = off[i]; g.len = n; g.rev = 0; g.pad = 0;
     if (n >= 2) {
-        int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
-        for (int64_t k = 1; k < n; k++) { x0 = min(x0, p[2 * k]); x1 = max(x1, p[2 * k]); y0 = min(y0, p[2 * k + 1]); y1 = max(y1, p[2 * k + 1]); }
+        const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;      // bbox from vfeatures (long polylines: block-parallel)
         double d = (double)max(x1 - x0, y1 - y0);
         if (d <= P.tap_diam && d <= P.tap_max_dim && n <= (int64_t)P.tap_max_v) {      // the vertex test is evaluated last in the reference but decides alone
             double per = (double)vs::pairwise_seglen_sum<0>(p, n);
@@ -53,7 +52,15 @@ __global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict
 
 // ================================================================= A2: resample (08:53-64)
 struct RsInfo { int64_t n_eff; double total; unsigned m; unsigned pass; };
-// sequential float32 cumsum per polyline (np.cumsum), one lane per polyline
+// sequential float32 cumsum per polyline (np.cumsum): one lane per short polyline; long polylines (k_cumlen_long) use one
+// wavefront: 64 segment lengths are computed / loaded by the lanes, the strictly sequential chain of float adds then runs
+// over them with v_readlane (the order of additions, and therefore every rounding, is the reference's)
+__device__ __forceinline__ void rs_finish(RsInfo& r, float acc, int64_t n, double step) {
+    r.total = (double)acc;
+    if (r.total <= step) { r.pass = 1; r.m = (unsigned)n; }
+    else r.m = (unsigned)ceil(r.total / step);
+    if (r.m < 2) r.m = 0;                                                             // len(S) < 2 -> nothing is drawn or stamped (08:130)
+}
 __global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
                                                  float* __restrict__ cum, RsInfo* __restrict__ info) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,14 +73,39 @@ __global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off,
     if (n >= 2) {
         if (n > 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;    // _is_closed inside _resample_arclen (08:56)
         r.n_eff = n;
-        float acc = 0.f; s[0] = 0.f;
-        for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32(p, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
-        r.total = (double)acc;
-        if (r.total <= step) { r.pass = 1; r.m = (unsigned)n; }
-        else r.m = (unsigned)ceil(r.total / step);
-        if (r.m < 2) r.m = 0;                                                         // len(S) < 2 -> nothing is drawn or stamped (08:130)
+        if (n <= ORIP_LONG_POLY) {
+            float acc = 0.f; s[0] = 0.f;
+            for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32(p, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
+            rs_finish(r, acc, n, step);
+        }
     }
     info[i] = r;
+}
+__global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
+                                                     float* __restrict__ cum, RsInfo* __restrict__ info) {
+    const int lane = threadIdx.x;
+    for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
+        RsInfo r = info[i];
+        const int64_t n = r.n_eff;
+        if (n <= ORIP_LONG_POLY) continue;
+        const int32_t* p = pts + 2 * off[i]; float* s = cum + off[i];
+        const int64_t nseg = n - 1;
+        float acc = 0.f;
+        if (lane == 0) s[0] = 0.f;
+        for (int64_t base = 0; base < nseg; base += 64) {
+            int64_t k = base + lane;
+            float sl = (k < nseg) ? vs::seg_len_f32(p, k) : 0.f;
+            float pre = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sl), j));
+                acc = __fadd_rn(acc, v);          // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
+                pre = (lane == j) ? acc : pre;
+            }
+            if (k < nseg) s[k + 1] = pre;
+        }
+        if (lane == 0) { rs_finish(r, acc, n, step); info[i] = r; }
+    }
 }
 __global__ __launch_bounds__(256) void k_rank_counts(const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t n, unsigned* __restrict__ mr) {
     int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -85,7 +117,7 @@ __device__ __forceinline__ int64_t ub_u32v(const unsigned* a, int64_t n, unsigne
     while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
     return lo;
 }
-struct SampleArrs { double* sx; double* sy; int* xi; int* yi; unsigned* rank; uint8_t* inc; };
+struct SampleArrs { double* sx; double* sy; double* dprev; int* xi; int* yi; unsigned* rank; uint8_t* inc; };
 __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A) {
@@ -118,6 +150,14 @@ __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off
     A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
 }
 
+// distance of every sample to its predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
+__global__ __launch_bounds__(256) void k_sample_dist(const unsigned* __restrict__ sbase, unsigned MS, SampleArrs A) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    unsigned b = sbase[A.rank[g]];
+    A.dprev[g] = (g > b) ? vs::norm2_f64(A.sx[g] - A.sx[g - 1], A.sy[g] - A.sy[g - 1]) : 0.0;
+}
+
 // ================================================================= A3: tail simulation (08:139-155), one lane per polyline
 __global__ __launch_bounds__(128) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A,
                                                    unsigned* __restrict__ npop, int* __restrict__ capprev) {
@@ -125,16 +165,16 @@ __global__ __launch_bounds__(128) void k_tail_sim(const unsigned* __restrict__ s
     if (r >= n_rank) return;
     unsigned b = sbase[r], e = sbase[r + 1];
     if (e <= b) return;
-    const double* X = A.sx + b; const double* Y = A.sy + b; const uint8_t* IN = A.inc + b;
+    const double* D = A.dprev + b; const uint8_t* IN = A.inc + b;
     unsigned m = e - b, head = 0; double tail_len = 0.0;
     int last_in = -1;
     auto pop_stamp = [&](unsigned j) { if (IN[j]) { capprev[b + j] = last_in; last_in = (int)j; } else capprev[b + j] = -2; };
     for (unsigned j = 0; j < m; j++) {
-        if (j > head) tail_len += vs::norm2_f64(X[j] - X[j - 1], Y[j] - Y[j - 1]);          // tail = samples [head, j)
+        if (j > head) tail_len += D[j];          // tail = samples [head, j)
         // while tail and tail_len > limit: pop
         while (head <= j && tail_len > tail_len_px) {
             unsigned o = head; head++;
-            if (head <= j) tail_len -= vs::norm2_f64(X[head] - X[o], Y[head] - Y[o]); else tail_len = 0.0;
+            if (head <= j) tail_len -= D[head]; else tail_len = 0.0;
             pop_stamp(o);
         }
         npop[b + j] = head;
@@ -537,7 +577,10 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     HIPC(c, LN(c).vtmp[2].ensure((size_t)(n + 1) * (16 + 8 + 2 * sizeof(GatherDesc)) + 256));
     unsigned* is_tap = LN(c).vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (n + 1); unsigned* tap_scan = is_keep + (n + 1); unsigned* keep_scan = tap_scan + (n + 1);
     int2* tap_xy = (int2*)(keep_scan + (n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (n + 1)); GatherDesc* kd2 = kd + (n + 1);
-    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, is_tap, is_keep, tap_xy, kd); }
+    HIPC(c, LN(c).vtmp[10].ensure((size_t)n * sizeof(PolyFeat) + 64));
+    PolyFeat* sfeat = LN(c).vtmp[10].as<PolyFeat>();
+    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, 0, sfeat));
+    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, sfeat, is_tap, is_keep, tap_xy, kd); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
     unsigned nt = 0, nk = 0;
@@ -586,7 +629,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         // ---- A1: order by perimeter, descending, stable
         HIPC(c, LN(c).vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
         PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
-        { ProfScope ps(c, "k_poly_features"); hipLaunchKernelGGL(k_poly_features, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, 1, feat); }
+        ORIP_TRY(vfeatures(c, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, kept0.p.total, 1, feat));
         HIPC(c, LN(c).vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
         float* kin = LN(c).vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
         unsigned* mr = ord + nk; unsigned* sbase = mr + (nk + 1); RsInfo* info = (RsInfo*)(sbase + (nk + 1) + 2);   // (6 nk + 4) dwords: 8-byte aligned
@@ -597,16 +640,18 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
+        if (kept0.p.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
         unsigned MS = 0;
         ORIP_TRY(vread(c, &MS, sbase + nk));
         if (MS > 0) {
             if (MS > 0x7ffffff0u) ORIP_FAIL(c, "too many samples");
-            HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
-            SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.xi = (int*)(A.sy + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
+            HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
+            SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.dprev = A.sy + MS; A.xi = (int*)(A.dprev + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
             unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
             { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
+            hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             // ---- A3
             { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop, capprev); }
             // ---- A4: de-duplicated capsules -> min-sequence canvas
@@ -647,7 +692,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         HIPC(c, LN(c).vtmp[6].ensure((size_t)n2 * sizeof(PolyFeat) + (size_t)(n2 + 1) * (4 + 4 + 4) + (size_t)n2 * sizeof(GroupInfo) + 256));
         PolyFeat* f2 = LN(c).vtmp[6].as<PolyFeat>(); int* par = (int*)(f2 + n2); unsigned* is_root = (unsigned*)(par + (n2 + 1)); unsigned* root_scan = is_root + (n2 + 1);
         GroupInfo* grp = (GroupInfo*)(root_scan + (n2 + 1) + ((3 * (n2 + 1)) & 1));
-        hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n2, 128)), dim3(128), 0, LN(c).stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, 1, f2);
+        ORIP_TRY(vfeatures(c, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, 1, f2));
         hipLaunchKernelGGL(k_iota, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, par, (int)n2);
         { ProfScope ps(c, "k_bbox_pairs"); hipLaunchKernelGGL(k_bbox_pairs, dim3((unsigned)std::min<int64_t>(n2, 8192)), dim3(256), 0, LN(c).stream, f2, (int)n2, exp, par); }
         hipLaunchKernelGGL(k_group_init, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, grp, (int)n2);

@@ -121,14 +121,13 @@ int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsig
 
 // ---- _tiny_and_taps (10:99-118) ----
 // cls: 0 drop, 1 tap, 2 keep
-__global__ __launch_bounds__(128) void k_tiny_taps10(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params10 P,
+__global__ __launch_bounds__(128) void k_tiny_taps10(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params10 P, const PolyFeat* __restrict__ feat,
                                                       unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_polys) return;
     if (i == n_polys) { is_tap[i] = 0; is_keep[i] = 0; return; }
     const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
-    int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
-    for (int64_t k = 1; k < n; k++) { x0 = min(x0, p[2 * k]); x1 = max(x1, p[2 * k]); y0 = min(y0, p[2 * k + 1]); y1 = max(y1, p[2 * k + 1]); }
+    const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;
     unsigned tap = 0, keep = 0;
     double big = fmax(P.tap_diam, P.min_keep) + 2.0;
     if ((double)max(x1 - x0, y1 - y0) > big) keep = 1;      // enclosing diameter >= bbox extent > both thresholds: no circle needed
@@ -285,7 +284,10 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
         int2* tap_xy = (int2*)(keep_scan + (cut.n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (cut.n + 1));
         int64_t n_seq = Tin.n;
         if (cut.n > 0) {
-            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, is_tap, is_keep, tap_xy);
+            HIPC(c, LN(c).vtmp[10].ensure((size_t)cut.n * sizeof(PolyFeat) + 64));
+            PolyFeat* cfeat = LN(c).vtmp[10].as<PolyFeat>();
+            ORIP_TRY(vfeatures(c, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, cut.total, 0, cfeat));
+            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, cfeat, is_tap, is_keep, tap_xy);
             ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
             ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));
             unsigned a = 0, b = 0;

@@ -4,7 +4,10 @@
 //   * the 8 neighbours of the current pixel are probed by lanes 0..7 in one load each; the NEIGH8-ordered choice is a
 //     ballot + find-first-set, so a step costs one memory round trip instead of up to eight dependent ones;
 //   * the raster-ordered scans for the next endpoint / leftover pixel test 64 list entries per step (ballot);
-//   * every decision is taken from wave-uniform values (ballot masks, broadcasts), lane 0 does all stores.
+//   * every decision is taken from wave-uniform values (ballot masks, broadcasts), lane 0 does all stores;
+//   * no per-step fence: the pixel marked at step t is the current pixel of step t+1 (never one of its own neighbours), its
+//     predecessor is excluded as `prev`, and older marks precede a probe load whose result was already waited for (vmcnt
+//     retires in issue order); one fence per walk orders the marks before the next raster scan.
 // The same source is compiled with g++ by tests/host/walk_harness.cpp, where a "wave" is emulated by plain loops, so
 // the walk logic (phases, guards, cycle fast-forward) is unit-tested on the CPU as well (test infrastructure).
 #pragma once
@@ -122,7 +125,7 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
         unsigned s = A.lin[q];
         int px = (int)(s % W), py = (int)(s / W), pvx = -1, pvy = -1;
         unsigned long long len = 1; emit(wpos, px, py);
-        mark(s, ST_FG | ST_END); wv.fence();
+        mark(s, ST_FG | ST_END);
         long long guard = 0;
         while (true) {
             unsigned m_any, m_unvis; u8 myv;
@@ -132,12 +135,13 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
             int nx = px + NBX[k], ny = py + NBY[k];
             u8 v = wv.value_of(myv, k);
             emit(wpos + len, nx, ny); len++;
-            mark((size_t)ny * W + nx, v); wv.fence();
+            mark((size_t)ny * W + nx, v);
             pvx = px; pvy = py; px = nx; py = ny;
             if (v & (ST_JUN | ST_END)) break;
             guard++;
             if (guard > total_fg * 2) break;
         }
+        wv.fence();       // marks of this walk are complete before the next scan
         if (len >= 5) {   // >=2 to be a path (04:168) and >=5 to survive vectorize_layer (04:224)
             n_pts += len; n_paths++;
             if (WRITE) { wpos += len; if (wv.leader()) off[wpath + 1] = (int64_t)wpos; wpath++; }
@@ -149,7 +153,7 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
         const int x0 = (int)(s % W), y0 = (int)(s / W);
         int px = x0, py = y0, pvx = -1, pvy = -1;
         unsigned long long len = 1; emit(wpos, px, py);
-        { u8 sv = st[s]; mark(s, sv); wv.fence(); }
+        { u8 sv = st[s]; mark(s, sv); }
         long long guard = 0;
         // Brent cycle detection on the (prev,cur) state; reset whenever a fresh pixel is consumed
         int tpx = -2, tpy = -2, tcx = -2, tcy = -2; long long power = 1, lam = 0;
@@ -162,7 +166,7 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
             int k = ffs8(m);
             int nx = px + NBX[k], ny = py + NBY[k];
             emit(wpos + len, nx, ny); len++;
-            if (fresh) { mark((size_t)ny * W + nx, wv.value_of(myv, k)); wv.fence(); }
+            if (fresh) mark((size_t)ny * W + nx, wv.value_of(myv, k));
             pvx = px; pvy = py; px = nx; py = ny;
             if (px == x0 && py == y0) break;
             guard++;
@@ -198,6 +202,7 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
                 if (lam == power) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power <<= 1; lam = 0; }
             }
         }
+        wv.fence();
         if (len >= 2) {
             int ddx = x0 - px, ddy = y0 - py;
             if (ddx * ddx + ddy * ddy < 3) {   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}

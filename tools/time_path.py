@@ -24,16 +24,14 @@ for rep in range(2):
     lap("contours", lambda: d.find_contours())
     tot = [d.polys_size(L.SLOT_CONTOURS, l) for l in range(K)]
     sx, sy, dx, dy = scale_factors(cfg, size, size)
-    lap("scale", lambda: [d.scale_vectors(l, sx, sy, dx, dy) for l in range(K)])
-    lap("sort07", lambda: [d.sort_contours(l) for l in range(K)])
+    lap("scale", lambda: S.for_each_layer(lambda l: d.scale_vectors(l, sx, sy, dx, dy), range(K)))
+    lap("sort07", lambda: S.for_each_layer(lambda l: d.sort_contours(l), range(K)))
     p8 = S.params08(cfg)
-    for l in range(K):
-        lap("dedup08", lambda: d.dedup_layer(l, p8))
-        print(f"   08 layer {l}: cum {T['dedup08']:.3f}s lines={d.polys_size(L.SLOT_LINES_INTRA, l)}", flush=True)
+    lap("dedup08", lambda: S.for_each_layer(lambda l: d.dedup_layer(l, p8), range(K)))
     lnames = S.cluster_names(cfg)[:K]
     order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), cfg.color_names.index(lnames[l])))
     lap("cross10", lambda: d.dedup_cross(order, S.params10(cfg)))
-    lap("order12", lambda: [d.plot_order(l, S.r_insert12(cfg)) for l in range(K)])
+    lap("order12", lambda: S.for_each_layer(lambda l: d.plot_order(l, S.r_insert12(cfg)), range(K)))
     total = sum(v for k, v in T.items() if k != "set_image")
     print(f"rep {rep} size {size} K {K}: contours n/pts per layer {tot}")
     print("   " + "  ".join(f"{k}={v*1e3:.1f}ms" for k, v in T.items()) + f"  | total(02-12)={total*1e3:.1f}ms -> {size*size/1e6/total:.2f} Mpx/s", flush=True)
