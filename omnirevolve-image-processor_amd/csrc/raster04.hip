@@ -144,15 +144,34 @@ __global__ __launch_bounds__(256) void k_comp_sizes(const unsigned* __restrict__
     if (c < nc) { size[c] = cs[c + 1] - cs[c]; idx[c] = c; }
 }
 
-// one block per descriptor (grid-stride): dst[pos + j] = dst[pos - lam + (j % lam)]
+// one block per descriptor (grid-stride).  kind 0: dst[pos + j] = dst[pos - lam + (j % lam)] (tail periodic within its own output);
+// kind 1: the tail is a recorded trajectory of the bounce log: entry i+1+j, wrapping from `end` to `cyc_begin`.
 __global__ __launch_bounds__(256) void k_expand_cycles(const unsigned long long* __restrict__ desc, const unsigned* __restrict__ n_desc, WalkArgs A) {
     unsigned nd = min(*n_desc, A.desc_cap);
     for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
         const unsigned long long* e = desc + 4ull * d;
-        int layer = (int)e[0]; unsigned long long pos = e[1], lam = e[2], cnt = e[3];
+        int layer = (int)(e[0] & 0xffffffffu); int kind = (int)(e[0] >> 32);
+        unsigned long long pos = e[1], cnt = e[3];
         int2* out = reinterpret_cast<int2*>(A.pts[layer]);
-        for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) out[pos + j] = out[pos - lam + (j % lam)];
+        if (kind == 0) {
+            unsigned long long lam = e[2];
+            for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) out[pos + j] = out[pos - lam + (j % lam)];
+        } else {
+            const unsigned i = (unsigned)e[2];
+            const unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
+            const unsigned long long lam = en - cb;
+            for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) {
+                unsigned long long f = (unsigned long long)i + 1 + j;
+                if (f >= en) f = cb + (f - en) % lam;
+                unsigned l = A.logbuf[3ull * f] >> 3;
+                out[pos + j] = make_int2((int)(l % (unsigned)A.W), (int)(l / (unsigned)A.W));
+            }
+        }
     }
+}
+__global__ __launch_bounds__(256) void k_fill_qidx(const unsigned* __restrict__ keys, const unsigned* __restrict__ lin, int64_t m, int64_t plane, int* __restrict__ qidx) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) qidx[plane * (keys[i] >> 26) + lin[i]] = (int)i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -261,6 +280,16 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     unsigned* comp_paths = (unsigned*)(pts_base + (NC + 1)); unsigned* path_base = comp_paths + (NC + 1);
     HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, LN(c).stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, LN(c).stream));
     A.comp_pts = comp_pts; A.comp_paths = comp_paths; A.pts_base = pts_base; A.path_base = path_base;
+    {   // bounce memo (walker.h): inverse pixel index, state memo, trajectory log, per-walk recipes
+        if ((uint64_t)6 * M + (uint64_t)64 * NC >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the bounce log");
+        hipLaunchKernelGGL(k_fill_qidx, dim3(cdiv(M, 256)), block, 0, LN(c).stream, keys, lin, (int64_t)M, (int64_t)plane, c->tmpD.as<int>());
+        HIPC(c, LN(c).vtmp[6].ensure((size_t)M * 32 + 64));
+        HIPC(c, LN(c).vtmp[7].ensure(((size_t)6 * M + (size_t)64 * NC + 8) * 12 + 64));
+        HIPC(c, LN(c).vtmp[8].ensure((size_t)M * 12 + 64));
+        HIPC(c, hipMemsetAsync(LN(c).vtmp[6].p, 0, (size_t)M * 32, LN(c).stream));
+        HIPC(c, hipMemsetAsync(LN(c).vtmp[8].p, 0, (size_t)M * 12, LN(c).stream));
+        A.qidx = c->tmpD.as<int>(); A.memo = LN(c).vtmp[6].as<unsigned>(); A.logbuf = LN(c).vtmp[7].as<unsigned>(); A.recipe = LN(c).vtmp[8].as<unsigned>();
+    }
     {   // schedule: components by size, descending
         HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 16 + 64));
         unsigned* szin = LN(c).vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;

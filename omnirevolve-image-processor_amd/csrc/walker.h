@@ -37,6 +37,11 @@ struct WalkArgs {
     // cycle expansion descriptors: (layer, dst point index, period, count)
     unsigned long long* desc; unsigned* n_desc; unsigned desc_cap;
     const unsigned* comp_order;        // optional: component processed by wave i (largest first), or nullptr
+    // bounce memo (count pass builds it, write pass replays per-walk recipes); all optional (nullptr = plain Brent)
+    const int* qidx;                   // [K,H,W]: index of a skeleton pixel in lin[] / keys[]
+    unsigned* memo;                    // [M*8]: log index + 1 of the state (pixel, incoming direction), 0 = unknown
+    unsigned* logbuf;                  // 3 words per entry: (lin << 3 | dir), cyc_begin, end  -- region of component c: [6*b + 64*c, +6*fg+64)
+    unsigned* recipe;                  // 3 words per start pixel q: own steps before the jump, log index + 1, remaining steps
 };
 
 namespace walk_detail {
@@ -45,6 +50,8 @@ struct Wave {
     int lane;
     __device__ Wave() : lane((int)(threadIdx.x & 63)) {}
     __device__ bool leader() const { return lane == 0; }
+    __device__ unsigned l0() const { return (unsigned)lane; }
+    __device__ unsigned nl() const { return 64u; }
     // probe the 8 neighbours of (px,py); returns masks over NEIGH8 indices
     __device__ void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) const {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
@@ -75,6 +82,8 @@ struct Wave {
 struct Wave {
     u8 nv[8];
     bool leader() const { return true; }
+    unsigned l0() const { return 0u; }
+    unsigned nl() const { return 1u; }
     void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
         m_any = m_unvis = 0; myv = 0;
@@ -148,6 +157,22 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
         }
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
+    // Bounce memo.  Once a walk has no unvisited neighbour left it follows the deterministic map (prev,cur) -> next over visited
+    // pixels.  That map never changes again for states that had no unvisited neighbour (the visited set only grows), so a
+    // trajectory recorded by an earlier walk of this component stays valid: a later walk that reaches a recorded state jumps
+    // straight to "the rest is that trajectory" instead of re-walking transient + cycle.  The count pass records trajectories
+    // (log), indexes their states (memo) and leaves one recipe per walk; the write pass replays the recipe.
+    const unsigned log_base = 6u * b + 64u * c, log_cap = 6u * (e - b) + 64u;
+    unsigned logcur = 0;
+    const bool use_memo = A.memo != nullptr && A.logbuf != nullptr && A.recipe != nullptr && A.qidx != nullptr;
+    const int* qidx = use_memo ? A.qidx + A.plane * layer : nullptr;
+    auto log_pos = [&](unsigned i, unsigned long long R, int& ox, int& oy) {   // position R steps after logged state i
+        unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
+        unsigned long long f = (unsigned long long)i + R;
+        if (f >= en) f = cb + (f - en) % (unsigned long long)(en - cb);
+        unsigned l = A.logbuf[3ull * f] >> 3;
+        ox = (int)(l % (unsigned)W); oy = (int)(l / (unsigned)W);
+    };
     for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG)) {
         unsigned s = A.lin[q];
         const int x0 = (int)(s % W), y0 = (int)(s / W);
@@ -155,9 +180,23 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
         unsigned long long len = 1; emit(wpos, px, py);
         { u8 sv = st[s]; mark(s, sv); }
         long long guard = 0;
+        unsigned rec_t = 0, rec_i1 = 0, rec_R = 0;
+        if (WRITE && use_memo) { rec_t = A.recipe[3ull * q]; rec_i1 = A.recipe[3ull * q + 1]; rec_R = A.recipe[3ull * q + 2]; }
+        const bool replay = WRITE && rec_i1 != 0;
+        unsigned nofresh = 0; bool log_ok = true;
         // Brent cycle detection on the (prev,cur) state; reset whenever a fresh pixel is consumed
         int tpx = -2, tpy = -2, tcx = -2, tcy = -2; long long power = 1, lam = 0;
         while (true) {
+            if (replay && len - 1 == rec_t) {     // the count pass jumped here: the rest is a recorded trajectory
+                unsigned slot = wv.fetch_inc(A.n_desc);
+                if (slot < A.desc_cap && wv.leader()) {
+                    unsigned long long* d = A.desc + 4ull * slot;
+                    d[0] = (unsigned long long)layer | (1ull << 32); d[1] = wpos + len; d[2] = (unsigned long long)(rec_i1 - 1); d[3] = (unsigned long long)rec_R;
+                }
+                log_pos(rec_i1 - 1, rec_R, px, py);
+                len += rec_R;
+                break;
+            }
             unsigned m_any, m_unvis; u8 myv;
             wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
             bool fresh = m_unvis != 0;
@@ -171,15 +210,46 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
             if (px == x0 && py == y0) break;
             guard++;
             if (guard > fg_comp * 4) break;
-            if (fresh) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power = 1; lam = 0; }
-            else {
+            if (fresh) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power = 1; lam = 0; nofresh = 0; log_ok = true; }
+            else if (!replay) {
+                if (!WRITE && use_memo) {
+                    const unsigned lin_cur = (unsigned)py * (unsigned)W + (unsigned)px;
+                    const unsigned qn = (unsigned)qidx[lin_cur];
+                    const unsigned mi = A.memo[8ull * qn + (unsigned)k];
+                    if (mi) {                      // recorded state: everything that follows is known
+                        const unsigned long long R = (unsigned long long)(fg_comp * 4 + 1 - guard);
+                        if (wv.leader()) { A.recipe[3ull * q] = (unsigned)(len - 1); A.recipe[3ull * q + 1] = mi; A.recipe[3ull * q + 2] = (unsigned)R; }
+                        log_pos(mi - 1, R, px, py);
+                        len += R;
+                        break;
+                    }
+                    if (log_ok && logcur + nofresh < log_cap) { if (wv.leader()) A.logbuf[3ull * (log_base + logcur + nofresh)] = (lin_cur << 3) | (unsigned)k; }
+                    else log_ok = false;
+                    nofresh++;
+                }
                 lam++;
                 if (pvx == tpx && pvy == tpy && px == tcx && py == tcy) {
                     // the last `lam` steps repeat forever (no fresh pixel is reachable from the cycle and the start is not on it):
                     // remaining steps until the guard fires
                     long long remaining = fg_comp * 4 + 1 - guard;
+                    bool recorded = false;
+                    if (!WRITE && use_memo && log_ok && nofresh >= (unsigned)lam) {
+                        // commit the trajectory [begin, end): transient then the cycle [end - lam, end); index its states
+                        const unsigned begin = log_base + logcur, end = begin + nofresh, cb = end - (unsigned)lam;
+                        wv.fence();
+                        for (unsigned t = wv.l0(); t < nofresh; t += wv.nl()) {
+                            const unsigned idx = begin + t;
+                            A.logbuf[3ull * idx + 1] = cb; A.logbuf[3ull * idx + 2] = end;
+                            const unsigned ld = A.logbuf[3ull * idx];
+                            A.memo[8ull * (unsigned)qidx[ld >> 3] + (ld & 7u)] = idx + 1;
+                        }
+                        wv.fence();
+                        logcur += nofresh;
+                        if (wv.leader()) { A.recipe[3ull * q] = (unsigned)(len - 1); A.recipe[3ull * q + 1] = end; /* (end-1)+1 */ A.recipe[3ull * q + 2] = (unsigned)remaining; }
+                        recorded = true;
+                    }
                     if (remaining > 0) {
-                        if (WRITE) {
+                        if (WRITE) {      // no recipe for this walk (log overflow in the count pass): the tail is periodic within its own output
                             unsigned slot = wv.fetch_inc(A.n_desc);
                             if (slot < A.desc_cap && wv.leader()) {
                                 unsigned long long* d = A.desc + 4ull * slot;
@@ -197,6 +267,7 @@ ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
                         }
                         len += (unsigned long long)remaining;
                     }
+                    (void)recorded;
                     break;
                 }
                 if (lam == power) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power <<= 1; lam = 0; }
