@@ -4,13 +4,14 @@
 //   k_skel_state      : per-pixel state byte (fg, endpoint deg==1, junction deg>=3)          (04:128-130)
 //   k_compact_*       : wavefront ballot / prefix-sum compaction of skeleton pixels in raster order (04:144,174)
 //   radix sort        : rocPRIM stable sort of (layer, component root) keys -> per-component pixel lists
-//   k_walk<WRITE>     : the centerline walker, one lane per component, exact serial semantics (04:137-205);
+//   k_trace / k_write_walks : the centerline walker (walker.h), exact serial semantics (04:137-205): one wave per component
 //                       runs twice (count, then write); the guard-bounded "bounce" tails of phase-2 walks are
 //                       detected as cycles of the (prev,cur) state and written by k_expand_cycles in parallel.
 #include "orip_ctx.h"
 #include "walker.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cstdlib>
 
 int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value);
 
@@ -133,45 +134,31 @@ __global__ __launch_bounds__(256) void k_clear_visited(u8* __restrict__ st, cons
 
 // one wavefront per component; wave i takes component comp_order[i] (largest components first, so the long serial
 // chains start immediately and the small ones fill in behind them)
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_walk(WalkArgs A) {
+__global__ __launch_bounds__(64) void k_trace(WalkArgs A) {
     unsigned i = blockIdx.x;
     if (i >= A.nc) return;
-    walk_component<WRITE>(A, A.comp_order ? A.comp_order[i] : i);
+    trace_component(A, A.comp_order ? A.comp_order[i] : i);
+}
+// one wavefront per kept walk
+__global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, const unsigned* __restrict__ kept_slots, unsigned n_kept) {
+    for (unsigned i = blockIdx.x; i < n_kept; i += gridDim.x) write_walk(A, kept_slots[i]);
 }
 __global__ __launch_bounds__(256) void k_comp_sizes(const unsigned* __restrict__ cs, unsigned nc, unsigned* __restrict__ size, unsigned* __restrict__ idx) {
     unsigned c = blockIdx.x * 256 + threadIdx.x;
     if (c < nc) { size[c] = cs[c + 1] - cs[c]; idx[c] = c; }
 }
-
-// one block per descriptor (grid-stride).  kind 0: dst[pos + j] = dst[pos - lam + (j % lam)] (tail periodic within its own output);
-// kind 1: the tail is a recorded trajectory of the bounce log: entry i+1+j, wrapping from `end` to `cyc_begin`.
-__global__ __launch_bounds__(256) void k_expand_cycles(const unsigned long long* __restrict__ desc, const unsigned* __restrict__ n_desc, WalkArgs A) {
-    unsigned nd = min(*n_desc, A.desc_cap);
-    for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
-        const unsigned long long* e = desc + 4ull * d;
-        int layer = (int)(e[0] & 0xffffffffu); int kind = (int)(e[0] >> 32);
-        unsigned long long pos = e[1], cnt = e[3];
-        int2* out = reinterpret_cast<int2*>(A.pts[layer]);
-        if (kind == 0) {
-            unsigned long long lam = e[2];
-            for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) out[pos + j] = out[pos - lam + (j % lam)];
-        } else {
-            const unsigned i = (unsigned)e[2];
-            const unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
-            const unsigned long long lam = en - cb;
-            for (unsigned long long j = threadIdx.x; j < cnt; j += blockDim.x) {
-                unsigned long long f = (unsigned long long)i + 1 + j;
-                if (f >= en) f = cb + (f - en) % lam;
-                unsigned l = A.logbuf[3ull * f] >> 3;
-                out[pos + j] = make_int2((int)(l % (unsigned)A.W), (int)(l / (unsigned)A.W));
-            }
-        }
-    }
-}
 __global__ __launch_bounds__(256) void k_fill_qidx(const unsigned* __restrict__ keys, const unsigned* __restrict__ lin, int64_t m, int64_t plane, int* __restrict__ qidx) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < m) qidx[plane * (keys[i] >> 26) + lin[i]] = (int)i;
+}
+__global__ __launch_bounds__(256) void k_winfo_lens(const WalkInfo* __restrict__ wi, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { unsigned l = wi[i].len_kept; lens[i] = l; kept[i] = l ? 1u : 0u; }
+    if (i == n) { lens[i] = 0; kept[i] = 0; }
+}
+__global__ __launch_bounds__(256) void k_kept_slots(const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off, unsigned n, unsigned* __restrict__ slots) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && kept[i]) slots[path_off[i]] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,23 +261,10 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     for (int l = K - 1; l >= 0; l--) if (layer_first[l] == NC && l + 1 <= K) layer_first[l] = layer_first[l + 1];
     layer_first[K] = NC;
     for (int l = 0; l < K; l++) A.total_fg[l] = (long long)h_cs[layer_first[l + 1]] - (long long)h_cs[layer_first[l]];
-    // ---- count pass
-    HIPC(c, LN(c).vtmp[4].ensure((size_t)(NC + 1) * (8 + 8 + 4 + 4) + 256));
-    unsigned long long* comp_pts = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_base = comp_pts + (NC + 1);
-    unsigned* comp_paths = (unsigned*)(pts_base + (NC + 1)); unsigned* path_base = comp_paths + (NC + 1);
-    HIPC(c, hipMemsetAsync(comp_pts + NC, 0, 8, LN(c).stream)); HIPC(c, hipMemsetAsync(comp_paths + NC, 0, 4, LN(c).stream));
-    A.comp_pts = comp_pts; A.comp_paths = comp_paths; A.pts_base = pts_base; A.path_base = path_base;
-    {   // bounce memo (walker.h): inverse pixel index, state memo, trajectory log, per-walk recipes
-        if ((uint64_t)6 * M + (uint64_t)64 * NC >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the bounce log");
-        hipLaunchKernelGGL(k_fill_qidx, dim3(cdiv(M, 256)), block, 0, LN(c).stream, keys, lin, (int64_t)M, (int64_t)plane, c->tmpD.as<int>());
-        HIPC(c, LN(c).vtmp[6].ensure((size_t)M * 32 + 64));
-        HIPC(c, LN(c).vtmp[7].ensure(((size_t)6 * M + (size_t)64 * NC + 8) * 12 + 64));
-        HIPC(c, LN(c).vtmp[8].ensure((size_t)M * 12 + 64));
-        HIPC(c, hipMemsetAsync(LN(c).vtmp[6].p, 0, (size_t)M * 32, LN(c).stream));
-        HIPC(c, hipMemsetAsync(LN(c).vtmp[8].p, 0, (size_t)M * 12, LN(c).stream));
-        A.qidx = c->tmpD.as<int>(); A.memo = LN(c).vtmp[6].as<unsigned>(); A.logbuf = LN(c).vtmp[7].as<unsigned>(); A.recipe = LN(c).vtmp[8].as<unsigned>();
-    }
-    {   // schedule: components by size, descending
+    // inverse pixel index (reuses the CCL parent planes, no longer needed) and the largest-first schedule
+    hipLaunchKernelGGL(k_fill_qidx, dim3(cdiv(M, 256)), block, 0, LN(c).stream, keys, lin, (int64_t)M, (int64_t)plane, c->tmpD.as<int>());
+    A.qidx = c->tmpD.as<int>();
+    {
         HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 16 + 64));
         unsigned* szin = LN(c).vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
         hipLaunchKernelGGL(k_comp_sizes, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, comp_start, NC, szin, idin);
@@ -302,33 +276,70 @@ extern "C" int orip_find_contours(orip_ctx* c) {
         HIPC(c, hipMemcpyAsync(LN(c).vtmp[3].p, idout, (size_t)NC * 4, hipMemcpyDeviceToDevice, LN(c).stream));
         A.comp_order = LN(c).vtmp[3].as<unsigned>();
     }
-    { ProfScope ps(c, "k_walk_count"); hipLaunchKernelGGL(k_walk<false>, dim3(NC), dim3(64), 0, LN(c).stream, A); }
-    HIPC(c, hipGetLastError());
-    ORIP_TRY(excl_scan<unsigned long long>(c, comp_pts, pts_base, (size_t)NC + 1, LN(c).tmpF));
-    ORIP_TRY(excl_scan<unsigned>(c, comp_paths, path_base, (size_t)NC + 1, LN(c).tmpF));
-    std::vector<unsigned long long> h_pb(NC + 1); std::vector<unsigned> h_qb(NC + 1);
-    HIPC(c, hipMemcpyAsync(h_pb.data(), pts_base, (size_t)(NC + 1) * 8, hipMemcpyDeviceToHost, LN(c).stream));
-    HIPC(c, hipMemcpyAsync(h_qb.data(), path_base, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, LN(c).stream));
+    // ---- trace pass (walker.h): one wave per component records step codes, bounce trajectories and one WalkInfo per walk
+    const bool walk_dbg = getenv("ORIP_WALK_DBG") != nullptr;
+    const unsigned nslots = 2u * M;
+    HIPC(c, LN(c).vtmp[6].ensure((size_t)M * 32 + 64));                       // memo
+    HIPC(c, LN(c).vtmp[8].ensure((size_t)nslots * sizeof(WalkInfo) + 64));    // walk records
+    int* d_over = LN(c).flags.as<int>() + 20;
+    A.memo = LN(c).vtmp[6].as<unsigned>(); A.winfo = LN(c).vtmp[8].as<WalkInfo>(); A.overflow = d_over;
+    for (unsigned F = 64;; F *= 4) {
+        if ((uint64_t)F * M + (uint64_t)256 * NC + 64 >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the walk logs (factor %u)", F);
+        const size_t nlog = (size_t)F * M + (size_t)64 * NC + 8, nstep = (size_t)F * M + (size_t)256 * NC + 8;
+        HIPC(c, LN(c).vtmp[7].ensure(nlog * 12 + 64));
+        HIPC(c, LN(c).vtmp[9].ensure(nstep + 64));
+        A.logbuf = LN(c).vtmp[7].as<unsigned>(); A.steplog = LN(c).vtmp[9].as<u8>(); A.cap_factor = F;
+        HIPC(c, hipMemsetAsync(A.memo, 0, (size_t)M * 32, LN(c).stream));
+        HIPC(c, hipMemsetAsync(A.winfo, 0, (size_t)nslots * sizeof(WalkInfo), LN(c).stream));
+        HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
+        if (walk_dbg) { HIPC(c, LN(c).vtmp[10].ensure((size_t)NC * 8 * 8 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[10].p, 0, (size_t)NC * 64, LN(c).stream)); A.dbg = LN(c).vtmp[10].as<unsigned long long>(); }
+        { ProfScope ps(c, "k_trace"); hipLaunchKernelGGL(k_trace, dim3(NC), dim3(64), 0, LN(c).stream, A); }
+        HIPC(c, hipGetLastError());
+        int over = 0;
+        HIPC(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, LN(c).stream));
+        HIPC(c, hipStreamSynchronize(LN(c).stream));
+        if (!over) break;
+        hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, LN(c).stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);   // retry with larger logs
+    }
+    if (walk_dbg) {
+        std::vector<unsigned long long> h((size_t)NC * 8); std::vector<unsigned> ho(NC);
+        hipMemcpy(h.data(), A.dbg, h.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(ho.data(), A.comp_order, (size_t)NC * 4, hipMemcpyDeviceToHost);
+        unsigned long long tot[8] = {0}; for (size_t i = 0; i < h.size(); i++) tot[i % 8] += h[i];
+        fprintf(stderr, "[walk dbg] NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n", NC, M, A.cap_factor, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6]);
+        for (int r = 0; r < 4 && r < (int)NC; r++) { const unsigned long long* d = &h[(size_t)ho[r] * 8]; fprintf(stderr, "   comp#%d fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n", r, d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]); }
+    }
+    // ---- offsets: exclusive scans over the walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
+    HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
+    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1);
+    unsigned* kept = (unsigned*)(pts_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
+    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A.winfo, nslots, lens, kept);
+    ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, (size_t)nslots + 1, LN(c).tmpF));
+    ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, (size_t)nslots + 1, LN(c).tmpF));
+    std::vector<unsigned long long> h_pb(K + 1); std::vector<unsigned> h_qb(K + 1);
+    for (int l = 0; l <= K; l++) {
+        const size_t sl = 2 * (size_t)h_cs[layer_first[l]];
+        HIPC(c, hipMemcpyAsync(&h_pb[l], pts_off + sl, 8, hipMemcpyDeviceToHost, LN(c).stream));
+        HIPC(c, hipMemcpyAsync(&h_qb[l], path_off + sl, 4, hipMemcpyDeviceToHost, LN(c).stream));
+    }
     HIPC(c, hipStreamSynchronize(LN(c).stream));
+    A.pts_off = pts_off; A.path_off = path_off;
     for (int l = 0; l < K; l++) {
         DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
-        A.layer_pts_base[l] = h_pb[layer_first[l]]; A.layer_path_base[l] = h_qb[layer_first[l]];
-        P.total = (int64_t)(h_pb[layer_first[l + 1]] - h_pb[layer_first[l]]);
-        P.n = (int64_t)(h_qb[layer_first[l + 1]] - h_qb[layer_first[l]]);
+        A.layer_pts_base[l] = h_pb[l]; A.layer_path_base[l] = h_qb[l];
+        P.total = (int64_t)(h_pb[l + 1] - h_pb[l]);
+        P.n = (int64_t)(h_qb[l + 1] - h_qb[l]);
         HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
         HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
         HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
         A.pts[l] = P.pts.as<int32_t>(); A.off[l] = P.off.as<int64_t>();
     }
-    // ---- write pass
-    hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, LN(c).stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);
-    // one descriptor per bounce walk; bounded by the number of skeleton pixels
-    HIPC(c, LN(c).vtmp[5].ensure((size_t)M * 32 + 64));
-    A.desc = LN(c).vtmp[5].as<unsigned long long>(); A.desc_cap = M;
-    A.n_desc = (unsigned*)(LN(c).flags.as<int>() + 16);
-    HIPC(c, hipMemsetAsync(A.n_desc, 0, 4, LN(c).stream));
-    { ProfScope ps(c, "k_walk_write"); hipLaunchKernelGGL(k_walk<true>, dim3(NC), dim3(64), 0, LN(c).stream, A); }
-    { ProfScope ps(c, "k_expand_cycles"); hipLaunchKernelGGL(k_expand_cycles, dim3(4096), block, 0, LN(c).stream, A.desc, A.n_desc, A); }
+    // ---- write pass: one wave per kept walk (prefix sums of direction codes + indexed copies of recorded tails)
+    const unsigned n_kept = h_qb[K];
+    if (n_kept) {
+        hipLaunchKernelGGL(k_kept_slots, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, nslots, kept_slots);
+        ProfScope ps(c, "k_write_walks");
+        hipLaunchKernelGGL(k_write_walks, dim3(std::min(n_kept, 262144u)), dim3(64), 0, LN(c).stream, A, kept_slots, n_kept);
+    }
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(LN(c).stream));   // the per-layer stages that follow run on other streams
     return 0;

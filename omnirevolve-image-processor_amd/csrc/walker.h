@@ -1,15 +1,21 @@
 // csrc/walker.h -- the centerline walker of stage 04 (04_find_contours.py trace_centerlines, 04:137-205).
 //
-// One WAVEFRONT walks one connected component with the reference's exact serial semantics:
-//   * the 8 neighbours of the current pixel are probed by lanes 0..7 in one load each; the NEIGH8-ordered choice is a
-//     ballot + find-first-set, so a step costs one memory round trip instead of up to eight dependent ones;
-//   * the raster-ordered scans for the next endpoint / leftover pixel test 64 list entries per step (ballot);
-//   * every decision is taken from wave-uniform values (ballot masks, broadcasts), lane 0 does all stores;
-//   * no per-step fence: the pixel marked at step t is the current pixel of step t+1 (never one of its own neighbours), its
-//     predecessor is excluded as `prev`, and older marks precede a probe load whose result was already waited for (vmcnt
-//     retires in issue order); one fence per walk orders the marks before the next raster scan.
-// The same source is compiled with g++ by tests/host/walk_harness.cpp, where a "wave" is emulated by plain loops, so
-// the walk logic (phases, guards, cycle fast-forward) is unit-tested on the CPU as well (test infrastructure).
+// trace_component: ONE WAVEFRONT walks one connected component with the reference's exact serial semantics and records
+// what it did instead of writing points:
+//   * the 8 neighbours of the current pixel are probed by lanes 0..7 from a 64x64 LDS window of the state plane; the
+//     NEIGH8-ordered choice is a ballot + find-first-set; the raster-ordered scans for the next endpoint / leftover pixel
+//     test 64 list entries per step; every decision is wave-uniform, lane 0 does all stores;
+//   * every step is logged as a 3-bit direction code (step log), every walk leaves one WalkInfo record;
+//   * bounce memo: once a walk has no unvisited neighbour left it follows the deterministic map (prev,cur) -> next over
+//     visited pixels.  For a state without unvisited neighbours that map never changes again (the visited set only grows),
+//     so a trajectory recorded once stays valid.  No-fresh states are logged (state log) and indexed (memo); reaching a state
+//     of the walk's own current run closes a cycle exactly (no Brent overhead), reaching a committed state of an earlier walk
+//     means "the rest is that trajectory".  Either way the guard-bounded tail (up to 4*fg+1 points) is not walked.
+// write_walk: one wavefront per recorded walk turns the record into points: a wave prefix sum over the direction codes for the
+// walk's own steps, and an indexed copy out of the state log for the tail.  No second serial pass, no visited state.
+//
+// The same source is compiled with g++ by tests/host/walk_harness.cpp, where a "wave" is emulated by plain loops, so the walk
+// logic (phases, guards, memo, cycle closing) is unit-tested on the CPU as well (test infrastructure).
 #pragma once
 #include <cstdint>
 #include "../../include/orip.h"
@@ -17,6 +23,8 @@
 #define ORIP_HD __host__ __device__
 #else
 #define ORIP_HD
+struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 #endif
 typedef uint8_t u8;
 #define ST_FG 1
@@ -24,47 +32,89 @@ typedef uint8_t u8;
 #define ST_END 4
 #define ST_JUN 8
 
+struct WalkInfo {            // one per potential walk: slot 2b+(q-b) for the endpoint walk starting at list index q, 2b+fg+(q-b) for a phase-2 walk
+    unsigned len_kept;       // total points if the path is kept (>= 5 points, 04:224), else 0
+    unsigned n_own;          // steps walked (points after the start pixel) before the recorded tail
+    unsigned step_begin;     // first direction code in the step log
+    unsigned log_i1;         // tail: state-log index + 1 of the state the walk stood on when it jumped (0 = no tail)
+    unsigned R;              // tail length in points
+    unsigned flags;          // bit0: append the start point again (04:203-204)
+};
+
 struct WalkArgs {
     int H, W; int64_t plane;
     u8* st;                            // [K,H,W] state bytes
     const unsigned* keys; const unsigned* lin; const unsigned* comp_start; unsigned nc;
     long long total_fg[ORIP_MAX_LAYERS];
-    // count pass outputs / write pass inputs
-    unsigned long long* comp_pts; unsigned* comp_paths;            // per component (kept paths only)
-    const unsigned long long* pts_base; const unsigned* path_base; // exclusive scans over components (global)
+    const unsigned* comp_order;        // optional: component processed by wave i (largest first), or nullptr
+    const int* qidx;                   // [K,H,W]: index of a skeleton pixel in lin[] / keys[]
+    unsigned* memo;                    // [M*8]: state-log index + 1 of the state (pixel, incoming direction), 0 = unknown
+    unsigned* logbuf;                  // state log, 3 words per entry: (lin << 3 | dir), cyc_begin, end (0 while provisional)
+    u8* steplog;                       // direction code of every step
+    unsigned cap_factor;               // regions of component c (b = comp_start[c], fg = size): state log [F*b + 64*c, + F*fg + 64), step log [F*b + 256*c, + F*fg + 256)
+    WalkInfo* winfo;                   // [2*M]
+    int* overflow;                     // set when a region was too small (host retries with a larger cap_factor)
+    // write pass
+    const unsigned long long* pts_off; const unsigned* path_off;   // exclusive scans over winfo (len_kept, kept)
     unsigned long long layer_pts_base[ORIP_MAX_LAYERS]; unsigned layer_path_base[ORIP_MAX_LAYERS];
     int32_t* pts[ORIP_MAX_LAYERS]; int64_t* off[ORIP_MAX_LAYERS];
-    // cycle expansion descriptors: (layer, dst point index, period, count)
-    unsigned long long* desc; unsigned* n_desc; unsigned desc_cap;
-    const unsigned* comp_order;        // optional: component processed by wave i (largest first), or nullptr
-    // bounce memo (count pass builds it, write pass replays per-walk recipes); all optional (nullptr = plain Brent)
-    const int* qidx;                   // [K,H,W]: index of a skeleton pixel in lin[] / keys[]
-    unsigned* memo;                    // [M*8]: log index + 1 of the state (pixel, incoming direction), 0 = unknown
-    unsigned* logbuf;                  // 3 words per entry: (lin << 3 | dir), cyc_begin, end  -- region of component c: [6*b + 64*c, +6*fg+64)
-    unsigned* recipe;                  // 3 words per start pixel q: own steps before the jump, log index + 1, remaining steps
+    unsigned long long* dbg;           // optional counters, 8 per component
 };
 
 namespace walk_detail {
 #if defined(__HIP_DEVICE_COMPILE__)
+#define WT 64
 struct Wave {
     int lane;
-    __device__ Wave() : lane((int)(threadIdx.x & 63)) {}
+    u8 (*tile)[WT + 4];
+    int tx0, ty0; bool have; unsigned nload;
+    __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0) {
+        __shared__ u8 lds_tile[WT][WT + 4];
+        tile = lds_tile;
+    }
     __device__ bool leader() const { return lane == 0; }
     __device__ unsigned l0() const { return (unsigned)lane; }
     __device__ unsigned nl() const { return 64u; }
+    __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
+    // lane 0 loads, everybody gets the value: lane 0 is also the only lane that stores these words, and a lane always sees its own earlier stores
+    __device__ unsigned ld0(const unsigned* p) const { unsigned v = 0; if (lane == 0) v = *p; return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ void load_tile(const u8* st, int W, int H, int cx, int cy) {
+        fence();                                                      // earlier marks have reached memory
+        tx0 = ((cx - WT / 2) >> 2) << 2; ty0 = cy - WT / 2;          // 4-byte aligned columns
+        const int y = ty0 + lane;
+        u8* row = tile[lane];
+        if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0u; }
+        else if ((W & 3) == 0 && tx0 >= 0 && tx0 + WT <= W) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (size_t)y * W + tx0);
+#pragma unroll
+            for (int j = 0; j < WT / 4; j++) *reinterpret_cast<uint32_t*>(row + 4 * j) = src[j];
+        } else {
+            for (int j = 0; j < WT; j++) { int x = tx0 + j; row[j] = (x >= 0 && x < W) ? st[(size_t)y * W + x] : (u8)0; }
+        }
+        have = true; nload++;
+        fence();
+    }
     // probe the 8 neighbours of (px,py); returns masks over NEIGH8 indices
-    __device__ void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) const {
-        const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    __device__ void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
+        if (!have || px - tx0 < 1 || px - tx0 > WT - 2 || py - ty0 < 1 || py - ty0 > WT - 2) load_tile(st, W, H, px, py);
         u8 v = 0; bool any = false;
         if (lane < 8) {
-            int xx = px + dxs[lane], yy = py + dys[lane];
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H) { v = st[(size_t)yy * W + xx]; any = (v & ST_FG) && !(xx == pvx && yy == pvy); }
+            int xx = px + (int)((0x9224u >> (2 * lane)) & 3u) - 1, yy = py + (int)((0xA940u >> (2 * lane)) & 3u) - 1;
+            v = tile[yy - ty0][xx - tx0];                         // out-of-image cells of the window hold 0
+            any = (v & ST_FG) && !(xx == pvx && yy == pvy);
         }
         myv = v;
         m_any = (unsigned)(__ballot(any) & 0xffu);
         m_unvis = (unsigned)(__ballot(any && !(v & ST_VIS)) & 0xffu);
     }
     __device__ u8 value_of(u8 myv, int k) const { return (u8)__shfl((int)myv, k, 64); }
+    // lane 0 marks pixel (x,y) visited: global memory and, when inside, the window
+    __device__ void mark(u8* st, int W, int x, int y, u8 v) {
+        if (lane == 0) {
+            st[(size_t)y * W + x] = (u8)(v | ST_VIS);
+            if (have && x >= tx0 && x < tx0 + WT && y >= ty0 && y < ty0 + WT) tile[y - ty0][x - tx0] = (u8)(v | ST_VIS);
+        }
+    }
     // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
     __device__ unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q += 64) {
@@ -75,15 +125,20 @@ struct Wave {
         }
         return e;
     }
-    __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
-    __device__ unsigned fetch_inc(unsigned* p) const { unsigned r = 0; if (lane == 0) r = atomicAdd(p, 1u); return (unsigned)__shfl((int)r, 0, 64); }
+    // inclusive prefix sums of (dx,dy) over the lanes; (ox,oy) = the lane's prefix, (tx,ty) = wave total
+    __device__ void scan2(int dx, int dy, int& ox, int& oy, int& tx, int& ty) const {
+        for (int o = 1; o < 64; o <<= 1) { int ax = __shfl_up(dx, o, 64), ay = __shfl_up(dy, o, 64); if (lane >= o) { dx += ax; dy += ay; } }
+        ox = dx; oy = dy; tx = __shfl(dx, 63, 64); ty = __shfl(dy, 63, 64);
+    }
 };
 #else
 struct Wave {
-    u8 nv[8];
+    u8 nv[8]; unsigned nload = 0;
     bool leader() const { return true; }
     unsigned l0() const { return 0u; }
     unsigned nl() const { return 1u; }
+    void fence() const {}
+    unsigned ld0(const unsigned* p) const { return *p; }
     void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
         m_any = m_unvis = 0; myv = 0;
@@ -95,195 +150,181 @@ struct Wave {
         }
     }
     u8 value_of(u8, int k) const { return nv[k]; }
+    void mark(u8* st, int W, int x, int y, u8 v) { st[(size_t)y * W + x] = (u8)(v | ST_VIS); }
     unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) return q; }
         return e;
     }
-    void fence() const {}
-    unsigned fetch_inc(unsigned* p) const { return (*p)++; }
+    void scan2(int dx, int dy, int& ox, int& oy, int& tx, int& ty) const { ox = dx; oy = dy; tx = dx; ty = dy; }
 };
 #endif
 ORIP_HD inline int ffs8(unsigned m) { int k = 0; while (!((m >> k) & 1u)) k++; return k; }
+// NEIGH8 (dx,dy) of 04:12 as packed 2-bit fields (value + 1)
+ORIP_HD inline int nbx(int k) { return (int)((0x9224u >> (2 * k)) & 3u) - 1; }
+ORIP_HD inline int nby(int k) { return (int)((0xA940u >> (2 * k)) & 3u) - 1; }
 }  // namespace walk_detail
 
-template <bool WRITE>
-ORIP_HD inline void walk_component(const WalkArgs& A, unsigned c) {
+ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     using namespace walk_detail;
-    const int NBX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};   // NEIGH8 (dx,dy), 04:12
-    const int NBY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
     Wave wv;
-    const unsigned b = A.comp_start[c], e = A.comp_start[c + 1];
+    const unsigned b = A.comp_start[c], e = A.comp_start[c + 1], fg = e - b;
     const int layer = (int)(A.keys[b] >> 26);
     u8* st = A.st + A.plane * layer;
+    const int* qidx = A.qidx + A.plane * layer;
     const int W = A.W, H = A.H;
-    const long long fg_comp = (long long)(e - b), total_fg = A.total_fg[layer];
-    unsigned long long n_pts = 0; unsigned n_paths = 0;
-    int32_t* out = nullptr; int64_t* off = nullptr; unsigned long long wpos = 0, wend = 0; unsigned wpath = 0;
-    if (WRITE) {
-        out = A.pts[layer]; off = A.off[layer];
-        wpos = A.pts_base[c] - A.layer_pts_base[layer];
-        wpath = A.path_base[c] - A.layer_path_base[layer];
-        wend = A.pts_base[c + 1] - A.layer_pts_base[layer];
-    }
-    // Paths shorter than 5 points are dropped after the fact, so their points must never land outside this component's own
-    // output range [wpos0, wend) (the range holds exactly the kept paths; anything inside it is overwritten by a later kept path).
-    auto emit = [&](unsigned long long pos, int x, int y) { if (WRITE && pos < wend && wv.leader()) { out[2 * pos] = x; out[2 * pos + 1] = y; } };
-    auto mark = [&](size_t j, u8 v) { if (wv.leader()) st[j] = (u8)(v | ST_VIS); };
-    // ---- phase 1: walks from endpoints (04:144-171)
+    const long long fg_comp = (long long)fg, total_fg = A.total_fg[layer];
+    const unsigned F = A.cap_factor;
+    const unsigned log_base = F * b + 64u * c, log_cap = F * fg + 64u;
+    const unsigned step_base = F * b + 256u * c, step_cap = F * fg + 256u;
+    unsigned logcur = 0, stepcur = 0;
+    bool over = false;
+    unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
+    auto put_step = [&](int k) { if (stepcur < step_cap) { if (wv.leader()) A.steplog[(size_t)step_base + stepcur] = (u8)k; } else over = true; stepcur++; };
+    auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
+        if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
+    };
+    // ---- phase 1: walks from endpoints (04:144-171); >= 2 points to be a path (04:168), >= 5 to survive vectorize_layer (04:224)
     for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG | ST_END); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG | ST_END)) {
         unsigned s = A.lin[q];
         int px = (int)(s % W), py = (int)(s / W), pvx = -1, pvy = -1;
-        unsigned long long len = 1; emit(wpos, px, py);
-        mark(s, ST_FG | ST_END);
-        long long guard = 0;
+        unsigned long long len = 1; const unsigned sbeg = step_base + stepcur;
+        wv.mark(st, W, px, py, ST_FG | ST_END);
+        long long guard = 0; d_w1++;
         while (true) {
             unsigned m_any, m_unvis; u8 myv;
             wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
             if (!m_unvis) break;
             int k = ffs8(m_unvis);
-            int nx = px + NBX[k], ny = py + NBY[k];
+            int nx = px + nbx(k), ny = py + nby(k);
             u8 v = wv.value_of(myv, k);
-            emit(wpos + len, nx, ny); len++;
-            mark((size_t)ny * W + nx, v);
+            put_step(k); len++; d_s1++;
+            wv.mark(st, W, nx, ny, v);
             pvx = px; pvy = py; px = nx; py = ny;
             if (v & (ST_JUN | ST_END)) break;
             guard++;
             if (guard > total_fg * 2) break;
         }
         wv.fence();       // marks of this walk are complete before the next scan
-        if (len >= 5) {   // >=2 to be a path (04:168) and >=5 to survive vectorize_layer (04:224)
-            n_pts += len; n_paths++;
-            if (WRITE) { wpos += len; if (wv.leader()) off[wpath + 1] = (int64_t)wpos; wpath++; }
-        }
+        finish(2u * b + (q - b), len, (unsigned)(len - 1), sbeg, 0u, 0u, 0u);
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
-    // Bounce memo.  Once a walk has no unvisited neighbour left it follows the deterministic map (prev,cur) -> next over visited
-    // pixels.  That map never changes again for states that had no unvisited neighbour (the visited set only grows), so a
-    // trajectory recorded by an earlier walk of this component stays valid: a later walk that reaches a recorded state jumps
-    // straight to "the rest is that trajectory" instead of re-walking transient + cycle.  The count pass records trajectories
-    // (log), indexes their states (memo) and leaves one recipe per walk; the write pass replays the recipe.
-    const unsigned log_base = 6u * b + 64u * c, log_cap = 6u * (e - b) + 64u;
-    unsigned logcur = 0;
-    const bool use_memo = A.memo != nullptr && A.logbuf != nullptr && A.recipe != nullptr && A.qidx != nullptr;
-    const int* qidx = use_memo ? A.qidx + A.plane * layer : nullptr;
     auto log_pos = [&](unsigned i, unsigned long long R, int& ox, int& oy) {   // position R steps after logged state i
-        unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
+        unsigned cb = wv.ld0(&A.logbuf[3ull * i + 1]), en = wv.ld0(&A.logbuf[3ull * i + 2]);
         unsigned long long f = (unsigned long long)i + R;
         if (f >= en) f = cb + (f - en) % (unsigned long long)(en - cb);
-        unsigned l = A.logbuf[3ull * f] >> 3;
+        unsigned l = wv.ld0(&A.logbuf[3ull * f]) >> 3;
         ox = (int)(l % (unsigned)W); oy = (int)(l / (unsigned)W);
     };
     for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG)) {
         unsigned s = A.lin[q];
         const int x0 = (int)(s % W), y0 = (int)(s / W);
         int px = x0, py = y0, pvx = -1, pvy = -1;
-        unsigned long long len = 1; emit(wpos, px, py);
-        { u8 sv = st[s]; mark(s, sv); }
-        long long guard = 0;
-        unsigned rec_t = 0, rec_i1 = 0, rec_R = 0;
-        if (WRITE && use_memo) { rec_t = A.recipe[3ull * q]; rec_i1 = A.recipe[3ull * q + 1]; rec_R = A.recipe[3ull * q + 2]; }
-        const bool replay = WRITE && rec_i1 != 0;
-        unsigned nofresh = 0; bool log_ok = true;
-        // Brent cycle detection on the (prev,cur) state; reset whenever a fresh pixel is consumed
-        int tpx = -2, tpy = -2, tcx = -2, tcy = -2; long long power = 1, lam = 0;
+        unsigned long long len = 1; const unsigned sbeg = step_base + stepcur;
+        { u8 sv = st[s]; wv.mark(st, W, px, py, sv); }
+        long long guard = 0; d_w2++;
+        unsigned n_own = 0, tail_i1 = 0, tail_R = 0;
+        unsigned nofresh = 0;                 // no-fresh states logged since the last fresh pixel: entries [run_begin, run_begin + nofresh)
         while (true) {
-            if (replay && len - 1 == rec_t) {     // the count pass jumped here: the rest is a recorded trajectory
-                unsigned slot = wv.fetch_inc(A.n_desc);
-                if (slot < A.desc_cap && wv.leader()) {
-                    unsigned long long* d = A.desc + 4ull * slot;
-                    d[0] = (unsigned long long)layer | (1ull << 32); d[1] = wpos + len; d[2] = (unsigned long long)(rec_i1 - 1); d[3] = (unsigned long long)rec_R;
-                }
-                log_pos(rec_i1 - 1, rec_R, px, py);
-                len += rec_R;
-                break;
-            }
             unsigned m_any, m_unvis; u8 myv;
             wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
             bool fresh = m_unvis != 0;
             unsigned m = fresh ? m_unvis : m_any;
             if (!m) break;
             int k = ffs8(m);
-            int nx = px + NBX[k], ny = py + NBY[k];
-            emit(wpos + len, nx, ny); len++;
-            if (fresh) mark((size_t)ny * W + nx, wv.value_of(myv, k));
+            int nx = px + nbx(k), ny = py + nby(k);
+            put_step(k); len++; n_own++; d_s2++;
+            if (fresh) wv.mark(st, W, nx, ny, wv.value_of(myv, k));
             pvx = px; pvy = py; px = nx; py = ny;
             if (px == x0 && py == y0) break;
             guard++;
             if (guard > fg_comp * 4) break;
-            if (fresh) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power = 1; lam = 0; nofresh = 0; log_ok = true; }
-            else if (!replay) {
-                if (!WRITE && use_memo) {
-                    const unsigned lin_cur = (unsigned)py * (unsigned)W + (unsigned)px;
-                    const unsigned qn = (unsigned)qidx[lin_cur];
-                    const unsigned mi = A.memo[8ull * qn + (unsigned)k];
-                    if (mi) {                      // recorded state: everything that follows is known
-                        const unsigned long long R = (unsigned long long)(fg_comp * 4 + 1 - guard);
-                        if (wv.leader()) { A.recipe[3ull * q] = (unsigned)(len - 1); A.recipe[3ull * q + 1] = mi; A.recipe[3ull * q + 2] = (unsigned)R; }
-                        log_pos(mi - 1, R, px, py);
-                        len += R;
-                        break;
-                    }
-                    if (log_ok && logcur + nofresh < log_cap) { if (wv.leader()) A.logbuf[3ull * (log_base + logcur + nofresh)] = (lin_cur << 3) | (unsigned)k; }
-                    else log_ok = false;
-                    nofresh++;
-                }
-                lam++;
-                if (pvx == tpx && pvy == tpy && px == tcx && py == tcy) {
-                    // the last `lam` steps repeat forever (no fresh pixel is reachable from the cycle and the start is not on it):
-                    // remaining steps until the guard fires
-                    long long remaining = fg_comp * 4 + 1 - guard;
-                    bool recorded = false;
-                    if (!WRITE && use_memo && log_ok && nofresh >= (unsigned)lam) {
-                        // commit the trajectory [begin, end): transient then the cycle [end - lam, end); index its states
-                        const unsigned begin = log_base + logcur, end = begin + nofresh, cb = end - (unsigned)lam;
-                        wv.fence();
-                        for (unsigned t = wv.l0(); t < nofresh; t += wv.nl()) {
-                            const unsigned idx = begin + t;
-                            A.logbuf[3ull * idx + 1] = cb; A.logbuf[3ull * idx + 2] = end;
-                            const unsigned ld = A.logbuf[3ull * idx];
-                            A.memo[8ull * (unsigned)qidx[ld >> 3] + (ld & 7u)] = idx + 1;
-                        }
-                        wv.fence();
+            if (fresh) { nofresh = 0; continue; }
+            const unsigned run_begin = log_base + logcur;
+            const unsigned state = (((unsigned)py * (unsigned)W + (unsigned)px) << 3) | (unsigned)k;
+            const unsigned qn = (unsigned)qidx[state >> 3];
+            const unsigned mi = wv.ld0(&A.memo[8ull * qn + (unsigned)k]);
+            bool jumped = false;
+            if (mi) {
+                const unsigned i = mi - 1;
+                const unsigned ld = wv.ld0(&A.logbuf[3ull * i]), en = wv.ld0(&A.logbuf[3ull * i + 2]);
+                if (ld == state) {
+                    const unsigned long long R = (unsigned long long)(fg_comp * 4 + 1 - guard);     // points still to come until the guard fires
+                    if (en != 0) {                                    // committed trajectory of an earlier walk
+                        d_hit++;
+                        tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
+                    } else if (i >= run_begin && i < run_begin + nofresh) {   // a state of this very run: the cycle [i, run_begin + nofresh) is closed
+                        d_det++;
+                        const unsigned end = run_begin + nofresh;
+                        if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { A.logbuf[3ull * (run_begin + t) + 1] = i; A.logbuf[3ull * (run_begin + t) + 2] = end; }
                         logcur += nofresh;
-                        if (wv.leader()) { A.recipe[3ull * q] = (unsigned)(len - 1); A.recipe[3ull * q + 1] = end; /* (end-1)+1 */ A.recipe[3ull * q + 2] = (unsigned)remaining; }
-                        recorded = true;
+                        tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
                     }
-                    if (remaining > 0) {
-                        if (WRITE) {      // no recipe for this walk (log overflow in the count pass): the tail is periodic within its own output
-                            unsigned slot = wv.fetch_inc(A.n_desc);
-                            if (slot < A.desc_cap && wv.leader()) {
-                                unsigned long long* d = A.desc + 4ull * slot;
-                                d[0] = (unsigned long long)layer; d[1] = wpos + len; d[2] = (unsigned long long)lam; d[3] = (unsigned long long)remaining;
-                            }
-                        }
-                        // position after the remaining steps = cycle point (remaining mod lam) steps ahead; needed for the closing test
-                        long long adv = remaining % lam;
-                        for (long long t = 0; t < adv; t++) {
-                            unsigned ma, mu; u8 mv;
-                            wv.probe(st, W, H, px, py, pvx, pvy, ma, mu, mv);
-                            int kk = ffs8(ma);
-                            int bx = px + NBX[kk], by = py + NBY[kk];
-                            pvx = px; pvy = py; px = bx; py = by;
-                        }
-                        len += (unsigned long long)remaining;
-                    }
-                    (void)recorded;
-                    break;
+                    if (jumped) { log_pos(i, R, px, py); len += R; }
                 }
-                if (lam == power) { tpx = pvx; tpy = pvy; tcx = px; tcy = py; power <<= 1; lam = 0; }
             }
+            if (jumped) break;
+            if (logcur + nofresh < log_cap) {                         // log the state (provisional until its run closes a cycle)
+                const unsigned idx = run_begin + nofresh;
+                if (wv.leader()) { A.logbuf[3ull * idx] = state; A.logbuf[3ull * idx + 2] = 0u; A.memo[8ull * qn + (unsigned)k] = idx + 1; }
+            } else over = true;
+            nofresh++;
         }
         wv.fence();
+        unsigned flags = 0;
         if (len >= 2) {
             int ddx = x0 - px, ddy = y0 - py;
-            if (ddx * ddx + ddy * ddy < 3) {   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}
-                emit(wpos + len, x0, y0); len++;
-            }
-            if (len >= 5) {
-                n_pts += len; n_paths++;
-                if (WRITE) { wpos += len; if (wv.leader()) off[wpath + 1] = (int64_t)wpos; wpath++; }
-            }
+            if (ddx * ddx + ddy * ddy < 3) { flags = 1; len++; }   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}: the start is appended again
+        }
+        finish(2u * b + fg + (q - b), len >= 2 ? len : 0, n_own, sbeg, tail_i1, tail_R, flags);
+    }
+    if (over && wv.leader()) *A.overflow = 1;
+    if (A.dbg && wv.leader()) { unsigned long long* d = A.dbg + 8ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg_comp; }
+}
+
+// Points of one recorded walk (winfo slot `slot`), written by one wavefront.
+ORIP_HD inline void write_walk(const WalkArgs& A, unsigned slot) {
+    using namespace walk_detail;
+    const WalkInfo wi = A.winfo[slot];
+    if (!wi.len_kept) return;
+    Wave wv;
+    // component of the slot: slots [2b, 2e) belong to the component whose list range is [b, e)
+    unsigned lo = 0, hi = A.nc;
+    while (lo < hi) { unsigned mid = (lo + hi) >> 1; if (2u * A.comp_start[mid + 1] <= slot) lo = mid + 1; else hi = mid; }
+    const unsigned c = lo, b = A.comp_start[c], fg = A.comp_start[c + 1] - b;
+    const unsigned rel = slot - 2u * b;
+    const unsigned q = b + (rel >= fg ? rel - fg : rel);
+    const int layer = (int)(A.keys[b] >> 26);
+    const int W = A.W;
+    const unsigned s = A.lin[q];
+    const int x0 = (int)(s % (unsigned)W), y0 = (int)(s / (unsigned)W);
+    int2* out = reinterpret_cast<int2*>(A.pts[layer]) + (A.pts_off[slot] - A.layer_pts_base[layer]);
+    if (wv.leader()) {
+        out[0] = make_int2(x0, y0);
+        A.off[layer][A.path_off[slot] - A.layer_path_base[layer] + 1] = (int64_t)(A.pts_off[slot] - A.layer_pts_base[layer] + wi.len_kept);
+        if (wi.flags & 1u) out[wi.len_kept - 1] = make_int2(x0, y0);
+    }
+    // own steps: prefix sums of the direction vectors
+    int cx = x0, cy = y0;
+    for (unsigned base = 0; base < wi.n_own; base += wv.nl()) {
+        unsigned t = base + wv.l0();
+        int dx = 0, dy = 0;
+        if (t < wi.n_own) { int k = A.steplog[(size_t)wi.step_begin + t]; dx = nbx(k); dy = nby(k); }
+        int ox, oy, tx, ty;
+        wv.scan2(dx, dy, ox, oy, tx, ty);
+        if (t < wi.n_own) out[1 + t] = make_int2(cx + ox, cy + oy);
+        cx += tx; cy += ty;
+    }
+    // tail: recorded trajectory, entry i+1+j, wrapping from `end` to `cyc_begin`
+    if (wi.log_i1) {
+        const unsigned i = wi.log_i1 - 1;
+        const unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
+        const unsigned long long lam = en - cb;
+        int2* o2 = out + 1 + wi.n_own;
+        for (unsigned long long j = wv.l0(); j < wi.R; j += wv.nl()) {
+            unsigned long long f = (unsigned long long)i + 1 + j;
+            if (f >= en) f = cb + (f - en) % lam;
+            unsigned l = A.logbuf[3ull * f] >> 3;
+            o2[j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W));
         }
     }
-    if (!WRITE && wv.leader()) { A.comp_pts[c] = n_pts; A.comp_paths[c] = n_paths; }
 }

@@ -9,7 +9,7 @@
 #include "../../omnirevolve-image-processor_amd/csrc/walker.h"
 
 extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out, int64_t off_cap, int32_t* pts_out, int64_t pts_cap,
-                            int64_t* n_paths, int64_t* n_pts, int use_memo) {
+                            int64_t* n_paths, int64_t* n_pts, int cap_factor) {
     size_t N = (size_t)H * W;
     std::vector<uint8_t> st(N, 0);
     std::vector<int> root(N, -1);
@@ -46,33 +46,22 @@ extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out,
     unsigned NC = (unsigned)cs.size(); cs.push_back(M);
     WalkArgs A; memset(&A, 0, sizeof(A));
     A.H = H; A.W = W; A.plane = (int64_t)N; A.st = st.data(); A.keys = keys.data(); A.lin = lin.data(); A.comp_start = cs.data(); A.nc = NC;
-    A.total_fg[0] = M;
+    A.total_fg[0] = M; A.comp_order = nullptr;
     std::vector<int> qidx(N, -1); for (unsigned i = 0; i < M; i++) qidx[lin[i]] = (int)i;
-    std::vector<unsigned> memo((size_t)M * 8, 0), logbuf(((size_t)6 * M + 64 * (size_t)NC + 8) * 3, 0), recipe((size_t)M * 3, 0);
-    if (use_memo) { A.qidx = qidx.data(); A.memo = memo.data(); A.logbuf = logbuf.data(); A.recipe = recipe.data(); }
-    std::vector<unsigned long long> comp_pts(NC + 1, 0), pts_base(NC + 1, 0); std::vector<unsigned> comp_paths(NC + 1, 0), path_base(NC + 1, 0);
-    A.comp_pts = comp_pts.data(); A.comp_paths = comp_paths.data(); A.pts_base = pts_base.data(); A.path_base = path_base.data();
-    for (unsigned c = 0; c < NC; c++) walk_component<false>(A, c);
-    for (unsigned c = 0; c < NC; c++) { pts_base[c + 1] = pts_base[c] + comp_pts[c]; path_base[c + 1] = path_base[c] + comp_paths[c]; }
-    *n_paths = path_base[NC]; *n_pts = (int64_t)pts_base[NC];
+    const unsigned F = cap_factor > 0 ? (unsigned)cap_factor : 16u;
+    std::vector<unsigned> memo((size_t)M * 8, 0), logbuf(((size_t)F * M + 64 * (size_t)NC + 8) * 3, 0);
+    std::vector<uint8_t> steplog((size_t)F * M + 256 * (size_t)NC + 8, 0);
+    std::vector<WalkInfo> winfo((size_t)2 * M); memset(winfo.data(), 0, winfo.size() * sizeof(WalkInfo));
+    int over = 0;
+    A.qidx = qidx.data(); A.memo = memo.data(); A.logbuf = logbuf.data(); A.steplog = steplog.data(); A.cap_factor = F; A.winfo = winfo.data(); A.overflow = &over;
+    for (unsigned c = 0; c < NC; c++) trace_component(A, c);
+    if (over) return 2;     // the product retries with a larger factor; the test asks for one explicitly
+    const unsigned nslots = 2 * M;
+    std::vector<unsigned long long> pts_off(nslots + 1, 0); std::vector<unsigned> path_off(nslots + 1, 0);
+    for (unsigned i = 0; i < nslots; i++) { pts_off[i + 1] = pts_off[i] + winfo[i].len_kept; path_off[i + 1] = path_off[i] + (winfo[i].len_kept ? 1u : 0u); }
+    *n_paths = path_off[nslots]; *n_pts = (int64_t)pts_off[nslots];
     if (*n_paths + 1 > off_cap || *n_pts > pts_cap) return 1;
-    for (unsigned i = 0; i < M; i++) st[lin[i]] &= (uint8_t)~ST_VIS;
-    std::vector<unsigned long long> desc((size_t)M * 4 + 4); unsigned n_desc = 0; A.comp_order = nullptr;
-    A.desc = desc.data(); A.n_desc = &n_desc; A.desc_cap = M;
-    A.pts[0] = pts_out; A.off[0] = off_out;
-    for (unsigned c = 0; c < NC; c++) walk_component<true>(A, c);
-    for (unsigned d = 0; d < n_desc; d++) {
-        unsigned long long pos = desc[4 * d + 1], cnt = desc[4 * d + 3]; int kind = (int)(desc[4 * d] >> 32);
-        if (kind == 0) {
-            unsigned long long lam = desc[4 * d + 2];
-            for (unsigned long long j = 0; j < cnt; j++) { pts_out[2 * (pos + j)] = pts_out[2 * (pos - lam + (j % lam))]; pts_out[2 * (pos + j) + 1] = pts_out[2 * (pos - lam + (j % lam)) + 1]; }
-        } else {
-            unsigned i = (unsigned)desc[4 * d + 2], cb = logbuf[3ull * i + 1], en = logbuf[3ull * i + 2];
-            for (unsigned long long j = 0; j < cnt; j++) {
-                unsigned long long f = (unsigned long long)i + 1 + j; if (f >= en) f = cb + (f - en) % (en - cb);
-                unsigned l = logbuf[3ull * f] >> 3; pts_out[2 * (pos + j)] = (int)(l % (unsigned)W); pts_out[2 * (pos + j) + 1] = (int)(l / (unsigned)W);
-            }
-        }
-    }
+    A.pts_off = pts_off.data(); A.path_off = path_off.data(); A.pts[0] = pts_out; A.off[0] = off_out;
+    for (unsigned i = 0; i < nslots; i++) write_walk(A, i);
     return 0;
 }
