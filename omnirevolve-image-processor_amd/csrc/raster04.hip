@@ -261,9 +261,7 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     for (int l = K - 1; l >= 0; l--) if (layer_first[l] == NC && l + 1 <= K) layer_first[l] = layer_first[l + 1];
     layer_first[K] = NC;
     for (int l = 0; l < K; l++) A.total_fg[l] = (long long)h_cs[layer_first[l + 1]] - (long long)h_cs[layer_first[l]];
-    // inverse pixel index (reuses the CCL parent planes, no longer needed) and the largest-first schedule
-    hipLaunchKernelGGL(k_fill_qidx, dim3(cdiv(M, 256)), block, 0, LN(c).stream, keys, lin, (int64_t)M, (int64_t)plane, c->tmpD.as<int>());
-    A.qidx = c->tmpD.as<int>();
+    // the largest-first schedule
     {
         HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 16 + 64));
         unsigned* szin = LN(c).vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
@@ -279,17 +277,18 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     // ---- trace pass (walker.h): one wave per component records step codes, bounce trajectories and one WalkInfo per walk
     const bool walk_dbg = getenv("ORIP_WALK_DBG") != nullptr;
     const unsigned nslots = 2u * M;
-    HIPC(c, LN(c).vtmp[6].ensure((size_t)M * 32 + 64));                       // memo
+    const size_t memo_bytes = plane * (size_t)K * 8 * 4;                      // memo plane: one word per (pixel, incoming direction)
+    HIPC(c, LN(c).vtmp[6].ensure(memo_bytes + 64));
     HIPC(c, LN(c).vtmp[8].ensure((size_t)nslots * sizeof(WalkInfo) + 64));    // walk records
     int* d_over = LN(c).flags.as<int>() + 20;
     A.memo = LN(c).vtmp[6].as<unsigned>(); A.winfo = LN(c).vtmp[8].as<WalkInfo>(); A.overflow = d_over;
     for (unsigned F = 64;; F *= 4) {
         if ((uint64_t)F * M + (uint64_t)256 * NC + 64 >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the walk logs (factor %u)", F);
         const size_t nlog = (size_t)F * M + (size_t)64 * NC + 8, nstep = (size_t)F * M + (size_t)256 * NC + 8;
-        HIPC(c, LN(c).vtmp[7].ensure(nlog * 12 + 64));
+        HIPC(c, LN(c).vtmp[7].ensure(nlog * 16 + 64));
         HIPC(c, LN(c).vtmp[9].ensure(nstep + 64));
         A.logbuf = LN(c).vtmp[7].as<unsigned>(); A.steplog = LN(c).vtmp[9].as<u8>(); A.cap_factor = F;
-        HIPC(c, hipMemsetAsync(A.memo, 0, (size_t)M * 32, LN(c).stream));
+        HIPC(c, hipMemsetAsync(A.memo, 0, memo_bytes, LN(c).stream));
         HIPC(c, hipMemsetAsync(A.winfo, 0, (size_t)nslots * sizeof(WalkInfo), LN(c).stream));
         HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
         if (walk_dbg) { HIPC(c, LN(c).vtmp[10].ensure((size_t)NC * 8 * 8 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[10].p, 0, (size_t)NC * 64, LN(c).stream)); A.dbg = LN(c).vtmp[10].as<unsigned long long>(); }

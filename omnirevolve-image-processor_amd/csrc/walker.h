@@ -47,9 +47,10 @@ struct WalkArgs {
     const unsigned* keys; const unsigned* lin; const unsigned* comp_start; unsigned nc;
     long long total_fg[ORIP_MAX_LAYERS];
     const unsigned* comp_order;        // optional: component processed by wave i (largest first), or nullptr
-    const int* qidx;                   // [K,H,W]: index of a skeleton pixel in lin[] / keys[]
-    unsigned* memo;                    // [M*8]: state-log index + 1 of the state (pixel, incoming direction), 0 = unknown
-    unsigned* logbuf;                  // state log, 3 words per entry: (lin << 3 | dir), cyc_begin, end (0 while provisional)
+    unsigned* memo;                    // [K,H,W,8]: state-log index + 1 of the state (pixel, incoming direction), 0 = unknown
+    unsigned* logbuf;                  // state log, 4 words per entry: (lin << 3 | dir), cont, end (0 while provisional), begin.  After entry end-1 the
+                                       // trajectory continues at entry `cont`: inside the record (cont >= begin) it is a cycle, otherwise the record is a
+                                       // transient that runs into an older record
     u8* steplog;                       // direction code of every step
     unsigned cap_factor;               // regions of component c (b = comp_start[c], fg = size): state log [F*b + 64*c, + F*fg + 64), step log [F*b + 256*c, + F*fg + 256)
     WalkInfo* winfo;                   // [2*M]
@@ -164,13 +165,24 @@ ORIP_HD inline int nbx(int k) { return (int)((0x9224u >> (2 * k)) & 3u) - 1; }
 ORIP_HD inline int nby(int k) { return (int)((0xA940u >> (2 * k)) & 3u) - 1; }
 }  // namespace walk_detail
 
+// Entry reached from the record of entry `rec` at raw position f (f >= rec): follow continuations until f lies inside a record.
+template <class WaveT>
+ORIP_HD inline unsigned long long log_resolve(const unsigned* logbuf, const WaveT& wv, unsigned rec, unsigned long long f) {
+    while (true) {
+        const unsigned cont = wv.ld0(&logbuf[4ull * rec + 1]), en = wv.ld0(&logbuf[4ull * rec + 2]), begin = wv.ld0(&logbuf[4ull * rec + 3]);
+        if (f < en) return f;
+        if (cont >= begin) return (unsigned long long)cont + (f - en) % (unsigned long long)(en - cont);   // cycle
+        f = (unsigned long long)cont + (f - en); rec = cont;                                               // transient -> older record
+    }
+}
+
 ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     using namespace walk_detail;
     Wave wv;
     const unsigned b = A.comp_start[c], e = A.comp_start[c + 1], fg = e - b;
     const int layer = (int)(A.keys[b] >> 26);
     u8* st = A.st + A.plane * layer;
-    const int* qidx = A.qidx + A.plane * layer;
+    unsigned* memo = A.memo + (size_t)A.plane * layer * 8;
     const int W = A.W, H = A.H;
     const long long fg_comp = (long long)fg, total_fg = A.total_fg[layer];
     const unsigned F = A.cap_factor;
@@ -209,10 +221,8 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
     auto log_pos = [&](unsigned i, unsigned long long R, int& ox, int& oy) {   // position R steps after logged state i
-        unsigned cb = wv.ld0(&A.logbuf[3ull * i + 1]), en = wv.ld0(&A.logbuf[3ull * i + 2]);
-        unsigned long long f = (unsigned long long)i + R;
-        if (f >= en) f = cb + (f - en) % (unsigned long long)(en - cb);
-        unsigned l = wv.ld0(&A.logbuf[3ull * f]) >> 3;
+        unsigned long long f = log_resolve(A.logbuf, wv, i, (unsigned long long)i + R);
+        unsigned l = wv.ld0(&A.logbuf[4ull * f]) >> 3;
         ox = (int)(l % (unsigned)W); oy = (int)(l / (unsigned)W);
     };
     for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG)) {
@@ -241,21 +251,22 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             if (fresh) { nofresh = 0; continue; }
             const unsigned run_begin = log_base + logcur;
             const unsigned state = (((unsigned)py * (unsigned)W + (unsigned)px) << 3) | (unsigned)k;
-            const unsigned qn = (unsigned)qidx[state >> 3];
-            const unsigned mi = wv.ld0(&A.memo[8ull * qn + (unsigned)k]);
+            const unsigned mi = wv.ld0(&memo[state]);
             bool jumped = false;
             if (mi) {
                 const unsigned i = mi - 1;
-                const unsigned ld = wv.ld0(&A.logbuf[3ull * i]), en = wv.ld0(&A.logbuf[3ull * i + 2]);
+                const unsigned ld = wv.ld0(&A.logbuf[4ull * i]), en = wv.ld0(&A.logbuf[4ull * i + 2]);
                 if (ld == state) {
                     const unsigned long long R = (unsigned long long)(fg_comp * 4 + 1 - guard);     // points still to come until the guard fires
                     if (en != 0) {                                    // committed trajectory of an earlier walk
                         d_hit++;
+                        // this run's own no-fresh states become a transient record that runs into entry i, so later walks can jump from them too
+                        if (nofresh) { const unsigned end = run_begin + nofresh; if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; } logcur += nofresh; }
                         tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
                     } else if (i >= run_begin && i < run_begin + nofresh) {   // a state of this very run: the cycle [i, run_begin + nofresh) is closed
                         d_det++;
                         const unsigned end = run_begin + nofresh;
-                        if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { A.logbuf[3ull * (run_begin + t) + 1] = i; A.logbuf[3ull * (run_begin + t) + 2] = end; }
+                        if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; }
                         logcur += nofresh;
                         tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
                     }
@@ -265,7 +276,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             if (jumped) break;
             if (logcur + nofresh < log_cap) {                         // log the state (provisional until its run closes a cycle)
                 const unsigned idx = run_begin + nofresh;
-                if (wv.leader()) { A.logbuf[3ull * idx] = state; A.logbuf[3ull * idx + 2] = 0u; A.memo[8ull * qn + (unsigned)k] = idx + 1; }
+                if (wv.leader()) { A.logbuf[4ull * idx] = state; A.logbuf[4ull * idx + 2] = 0u; memo[state] = idx + 1; }
             } else over = true;
             nofresh++;
         }
@@ -317,13 +328,17 @@ ORIP_HD inline void write_walk(const WalkArgs& A, unsigned slot) {
     // tail: recorded trajectory, entry i+1+j, wrapping from `end` to `cyc_begin`
     if (wi.log_i1) {
         const unsigned i = wi.log_i1 - 1;
-        const unsigned cb = A.logbuf[3ull * i + 1], en = A.logbuf[3ull * i + 2];
-        const unsigned long long lam = en - cb;
         int2* o2 = out + 1 + wi.n_own;
         for (unsigned long long j = wv.l0(); j < wi.R; j += wv.nl()) {
-            unsigned long long f = (unsigned long long)i + 1 + j;
-            if (f >= en) f = cb + (f - en) % lam;
-            unsigned l = A.logbuf[3ull * f] >> 3;
+            // entry i+1+j of the trajectory that starts at record(i): follow continuations (transient -> ... -> cycle)
+            unsigned rec = i; unsigned long long f = (unsigned long long)i + 1 + j;
+            while (true) {
+                const unsigned cont = A.logbuf[4ull * rec + 1], en = A.logbuf[4ull * rec + 2], begin = A.logbuf[4ull * rec + 3];
+                if (f < en) break;
+                if (cont >= begin) { f = (unsigned long long)cont + (f - en) % (unsigned long long)(en - cont); break; }
+                f = (unsigned long long)cont + (f - en); rec = cont;
+            }
+            unsigned l = A.logbuf[4ull * f] >> 3;
             o2[j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W));
         }
     }

@@ -47,13 +47,12 @@ extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out,
     WalkArgs A; memset(&A, 0, sizeof(A));
     A.H = H; A.W = W; A.plane = (int64_t)N; A.st = st.data(); A.keys = keys.data(); A.lin = lin.data(); A.comp_start = cs.data(); A.nc = NC;
     A.total_fg[0] = M; A.comp_order = nullptr;
-    std::vector<int> qidx(N, -1); for (unsigned i = 0; i < M; i++) qidx[lin[i]] = (int)i;
     const unsigned F = cap_factor > 0 ? (unsigned)cap_factor : 16u;
-    std::vector<unsigned> memo((size_t)M * 8, 0), logbuf(((size_t)F * M + 64 * (size_t)NC + 8) * 3, 0);
+    std::vector<unsigned> memo((size_t)N * 8, 0), logbuf(((size_t)F * M + 64 * (size_t)NC + 8) * 4, 0);
     std::vector<uint8_t> steplog((size_t)F * M + 256 * (size_t)NC + 8, 0);
     std::vector<WalkInfo> winfo((size_t)2 * M); memset(winfo.data(), 0, winfo.size() * sizeof(WalkInfo));
     int over = 0;
-    A.qidx = qidx.data(); A.memo = memo.data(); A.logbuf = logbuf.data(); A.steplog = steplog.data(); A.cap_factor = F; A.winfo = winfo.data(); A.overflow = &over;
+    A.memo = memo.data(); A.logbuf = logbuf.data(); A.steplog = steplog.data(); A.cap_factor = F; A.winfo = winfo.data(); A.overflow = &over;
     for (unsigned c = 0; c < NC; c++) trace_component(A, c);
     if (over) return 2;     // the product retries with a larger factor; the test asks for one explicitly
     const unsigned nslots = 2 * M;
