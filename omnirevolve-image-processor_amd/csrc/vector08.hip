@@ -158,28 +158,53 @@ __global__ __launch_bounds__(256) void k_sample_dist(const unsigned* __restrict_
     A.dprev[g] = (g > b) ? vs::norm2_f64(A.sx[g] - A.sx[g - 1], A.sy[g] - A.sy[g - 1]) : 0.0;
 }
 
-// ================================================================= A3: tail simulation (08:139-155), one lane per polyline
-__global__ __launch_bounds__(128) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A,
-                                                   unsigned* __restrict__ npop, int* __restrict__ capprev) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rank) return;
-    unsigned b = sbase[r], e = sbase[r + 1];
-    if (e <= b) return;
-    const double* D = A.dprev + b; const uint8_t* IN = A.inc + b;
-    unsigned m = e - b, head = 0; double tail_len = 0.0;
-    int last_in = -1;
-    auto pop_stamp = [&](unsigned j) { if (IN[j]) { capprev[b + j] = last_in; last_in = (int)j; } else capprev[b + j] = -2; };
-    for (unsigned j = 0; j < m; j++) {
-        if (j > head) tail_len += D[j];          // tail = samples [head, j)
-        // while tail and tail_len > limit: pop
-        while (head <= j && tail_len > tail_len_px) {
-            unsigned o = head; head++;
-            if (head <= j) tail_len -= D[head]; else tail_len = 0.0;
-            pop_stamp(o);
+// ================================================================= A3: tail simulation (08:139-155)
+// The tail length is a float64 running sum with data-dependent pops: strictly sequential per polyline.  One WAVEFRONT per
+// polyline: the distances are loaded 64 at a time (coalesced) and the wave-uniform recurrence picks them out of the lanes with
+// v_readlane, for the push stream and for the pop stream; the pop counts go back to memory 64 at a time.
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A, unsigned* __restrict__ npop) {
+    const int lane = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < n_rank; r += gridDim.x) {
+        const unsigned b = sbase[r], e = sbase[r + 1];
+        if (e <= b) continue;
+        const double* D = A.dprev + b; unsigned* NP = npop + b;
+        const unsigned m = e - b;
+        unsigned head = 0, jw = 0, hw = 0;
+        double dj = (lane < (int)m) ? D[lane] : 0.0, dh = dj, djn = 0.0;
+        if (64 + lane < (int)m && 64u < m) djn = D[64 + lane];
+        double tail_len = 0.0; unsigned nv = 0;
+        for (unsigned j = 0; j < m; j++) {
+            if (j - jw == 64u) {                     // next push window (prefetched one window ahead)
+                NP[jw + lane] = nv;
+                jw += 64u; dj = djn;
+                djn = (jw + 64u + lane < m) ? D[jw + 64u + lane] : 0.0;
+            }
+            if (j > head) tail_len = __dadd_rn(tail_len, rl_f64(dj, (int)(j - jw)));
+            while (head <= j && __builtin_amdgcn_readfirstlane((int)(tail_len > tail_len_px))) {
+                head++;
+                if (head <= j) {
+                    if (head - hw >= 64u) { hw = head & ~63u; dh = (hw + lane < m) ? D[hw + lane] : 0.0; }
+                    tail_len = __dsub_rn(tail_len, rl_f64(dh, (int)(head - hw)));
+                } else tail_len = 0.0;
+            }
+            nv = ((unsigned)lane == (j & 63u)) ? head : nv;
         }
-        npop[b + j] = head;
+        if (jw + lane < m) NP[jw + lane] = nv;
     }
-    for (unsigned o = head; o < m; o++) pop_stamp(o);     // final flush (08:173-180)
+}
+// previous in-canvas sample of the same polyline (the far end of the capsule stamped when sample j is popped, 08:151-155); -1: none, -2: j is off-canvas
+__global__ __launch_bounds__(256) void k_capprev(const unsigned* __restrict__ sbase, unsigned MS, SampleArrs A, int* __restrict__ capprev) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    if (!A.inc[g]) { capprev[g] = -2; return; }
+    const unsigned b = sbase[A.rank[g]];
+    int p = -1;
+    for (unsigned q = g; q > b; ) { q--; if (A.inc[q]) { p = (int)(q - b); break; } }
+    capprev[g] = p;
 }
 
 // ================================================================= A4: capsule de-duplication + min-sequence stamping
@@ -653,7 +678,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             // ---- A3
-            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop, capprev); }
+            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop); }
+            hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, capprev);
             // ---- A4: de-duplicated capsules -> min-sequence canvas
             HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
             unsigned* firstseq = LN(c).canvas.as<unsigned>();

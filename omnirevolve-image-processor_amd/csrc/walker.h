@@ -327,19 +327,25 @@ ORIP_HD inline void write_walk(const WalkArgs& A, unsigned slot) {
     }
     // tail: recorded trajectory, entry i+1+j, wrapping from `end` to `cyc_begin`
     if (wi.log_i1) {
+        // the tail is the trajectory after entry i: a chain of record pieces (rest of i's record, then the records it continues
+        // into) that ends in a cycle.  The chain is walked once per wave; each piece is a contiguous run of log entries.
         const unsigned i = wi.log_i1 - 1;
         int2* o2 = out + 1 + wi.n_own;
-        for (unsigned long long j = wv.l0(); j < wi.R; j += wv.nl()) {
-            // entry i+1+j of the trajectory that starts at record(i): follow continuations (transient -> ... -> cycle)
-            unsigned rec = i; unsigned long long f = (unsigned long long)i + 1 + j;
-            while (true) {
-                const unsigned cont = A.logbuf[4ull * rec + 1], en = A.logbuf[4ull * rec + 2], begin = A.logbuf[4ull * rec + 3];
-                if (f < en) break;
-                if (cont >= begin) { f = (unsigned long long)cont + (f - en) % (unsigned long long)(en - cont); break; }
-                f = (unsigned long long)cont + (f - en); rec = cont;
+        unsigned long long done = 0, f0 = (unsigned long long)i + 1; unsigned rec = i;
+        while (done < wi.R) {
+            const unsigned cont = A.logbuf[4ull * rec + 1], en = A.logbuf[4ull * rec + 2], begin = A.logbuf[4ull * rec + 3];
+            if (f0 < en) {
+                unsigned long long take = en - f0; if (take > wi.R - done) take = wi.R - done;
+                for (unsigned long long j = wv.l0(); j < take; j += wv.nl()) { unsigned l = A.logbuf[4ull * (f0 + j)] >> 3; o2[done + j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W)); }
+                done += take;
+                if (done >= wi.R) break;
             }
-            unsigned l = A.logbuf[4ull * f] >> 3;
-            o2[j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W));
+            if (cont >= begin) {           // cycle [cont, en): the rest of the tail
+                const unsigned long long lam = en - cont, rest = wi.R - done;
+                for (unsigned long long j = wv.l0(); j < rest; j += wv.nl()) { unsigned l = A.logbuf[4ull * (cont + j % lam)] >> 3; o2[done + j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W)); }
+                break;
+            }
+            f0 = cont; rec = cont;         // transient record exhausted: continue in the older record
         }
     }
 }
