@@ -279,9 +279,10 @@ __global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __
         for (int dx = -1; dx <= 1 && ok; dx++)
             for (int dy = -1; dy <= 1 && ok; dy++) {
                 unsigned long long key = cell_key(r, cx + dx, cy + dy);
-                long long lo = 0, hi = MS;
+                long long lo = b, hi = sbase[r + 1];          // the sorted keys of polyline r occupy exactly its own sample range
+                const long long seg_end = hi;
                 while (lo < hi) { long long mid = (lo + hi) >> 1; if (skeys[mid] < key) lo = mid + 1; else hi = mid; }
-                for (long long q = lo; q < (long long)MS && skeys[q] == key; q++) {
+                for (long long q = lo; q < seg_end && skeys[q] == key; q++) {
                     unsigned g2 = svals[q];
                     if (g2 >= limit) break;                     // buckets are in pop order
                     double ddx = __dsub_rn(A.sx[g2], x), ddy = __dsub_rn(A.sy[g2], y);

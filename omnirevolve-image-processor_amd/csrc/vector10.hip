@@ -11,6 +11,8 @@
 //              exact two-pass disc dilation (row pass with wave ballots, column pass)
 //   taps seq : sequential accept + immediate stamp (10:259-267) as one workgroup walking the tap list
 #include "vec_common.h"
+#include <chrono>
+#include <cstdlib>
 #define ORIP_PAD 64
 
 // ---- cut ----
@@ -120,27 +122,85 @@ int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsig
 }
 
 // ---- _tiny_and_taps (10:99-118) ----
-// cls: 0 drop, 1 tap, 2 keep
-__global__ __launch_bounds__(128) void k_tiny_taps10(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params10 P, const PolyFeat* __restrict__ feat,
-                                                      unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_polys) return;
-    if (i == n_polys) { is_tap[i] = 0; is_keep[i] = 0; return; }
-    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
-    const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;
-    unsigned tap = 0, keep = 0;
-    double big = fmax(P.tap_diam, P.min_keep) + 2.0;
-    if ((double)max(x1 - x0, y1 - y0) > big) keep = 1;      // enclosing diameter >= bbox extent > both thresholds: no circle needed
-    else {
-        float cx, cy, r; vs::min_enclosing_circle(p, n, cx, cy, r);
-        double d = 2.0 * (double)r;
-        if (d <= P.tap_diam) {
-            double per = vs::arc_length(p, n, false);
-            if (per <= P.tap_max_per && n <= (int64_t)P.tap_max_v) { tap = 1; tap_xy[i] = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy)); }
-        }
-        if (!tap && d >= P.min_keep) keep = 1;
+// cv::minEnclosingCircle (recalled OpenCV 4.x algorithm, see vec_serial.h) with one wavefront per polyline: the three nested
+// loops of the incremental algorithm are "skip points that are inside, update on the first one that is not", so each of them is
+// run as a 64-wide search for the next violating point; updates happen in exactly the sequential order.
+__device__ __forceinline__ int wave_first(bool pred) { unsigned long long m = __ballot(pred); return m ? (__ffsll((long long)m) - 1) : -1; }
+__device__ void mec_third_w(const int32_t* xy, int i, int j, vs::P2& c, float& radius, int lane) {
+    const float EPS = 1.0e-4f;
+    vs::P2 pi = vs::ipt(xy, i), pj = vs::ipt(xy, j);
+    c.x = (pj.x + pi.x) / 2.0f; c.y = (pj.y + pi.y) / 2.0f;
+    radius = (float)vs::nrm2(pj.x - pi.x, pj.y - pi.y) / 2.0f + EPS;
+    for (int k0 = 0; k0 < j;) {
+        int k = k0 + lane; bool viol = false;
+        if (k < j) { vs::P2 pk = vs::ipt(xy, k); viol = !(vs::nrm2(c.x - pk.x, c.y - pk.y) < (double)radius); }
+        int f = wave_first(viol);
+        if (f < 0) { k0 += 64; continue; }
+        int kk = k0 + f;
+        vs::P2 nc{0, 0}; float nr = 0;
+        vs::mec_circle3(pi, pj, vs::ipt(xy, kk), nc, nr);
+        if (nr > 0) { radius = nr; c = nc; }
+        k0 = kk + 1;
     }
-    is_tap[i] = tap; is_keep[i] = keep;
+}
+__device__ void mec_second_w(const int32_t* xy, int i, vs::P2& c, float& radius, int lane) {
+    const float EPS = 1.0e-4f;
+    vs::P2 p0 = vs::ipt(xy, 0), pi = vs::ipt(xy, i);
+    c.x = (p0.x + pi.x) / 2.0f; c.y = (p0.y + pi.y) / 2.0f;
+    radius = (float)vs::nrm2(p0.x - pi.x, p0.y - pi.y) / 2.0f + EPS;
+    for (int j0 = 1; j0 < i;) {
+        int j = j0 + lane; bool viol = false;
+        if (j < i) { vs::P2 pj = vs::ipt(xy, j); viol = !(vs::nrm2(c.x - pj.x, c.y - pj.y) < (double)radius); }
+        int f = wave_first(viol);
+        if (f < 0) { j0 += 64; continue; }
+        int jj = j0 + f;
+        vs::P2 nc{0, 0}; float nr = 0;
+        mec_third_w(xy, i, jj, nc, nr, lane);
+        if (nr > 0) { radius = nr; c = nc; }
+        j0 = jj + 1;
+    }
+}
+__device__ void mec_wave(const int32_t* xy, int n, float& cx, float& cy, float& r, int lane) {
+    if (n <= 2) { vs::min_enclosing_circle(xy, n, cx, cy, r); return; }
+    const float EPS = 1.0e-4f;
+    vs::P2 p0 = vs::ipt(xy, 0), p1 = vs::ipt(xy, 1);
+    vs::P2 c{(p0.x + p1.x) / 2.0f, (p0.y + p1.y) / 2.0f};
+    float radius = (float)vs::nrm2(p0.x - p1.x, p0.y - p1.y) / 2.0f + EPS;
+    for (int i0 = 2; i0 < n;) {
+        int i = i0 + lane; bool viol = false;
+        if (i < n) { vs::P2 pi = vs::ipt(xy, i); float d = (float)vs::nrm2(pi.x - c.x, pi.y - c.y); viol = !(d < radius); }
+        int f = wave_first(viol);
+        if (f < 0) { i0 += 64; continue; }
+        int ii = i0 + f;
+        vs::P2 nc{0, 0}; float nr = 0;
+        mec_second_w(xy, ii, nc, nr, lane);
+        if (nr > 0) { radius = nr; c = nc; }
+        i0 = ii + 1;
+    }
+    cx = c.x; cy = c.y; r = radius;
+}
+// one wavefront per polyline
+__global__ __launch_bounds__(64) void k_tiny_taps10(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params10 P, const PolyFeat* __restrict__ feat,
+                                                     unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy) {
+    const int lane = threadIdx.x;
+    for (int64_t i = blockIdx.x; i <= n_polys; i += gridDim.x) {
+        if (i == n_polys) { if (lane == 0) { is_tap[i] = 0; is_keep[i] = 0; } continue; }
+        const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
+        const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;
+        unsigned tap = 0, keep = 0; int2 txy = make_int2(0, 0);
+        double big = fmax(P.tap_diam, P.min_keep) + 2.0;
+        if ((double)max(x1 - x0, y1 - y0) > big) keep = 1;      // enclosing diameter >= bbox extent > both thresholds: no circle needed
+        else {
+            float cx, cy, r; mec_wave(p, (int)n, cx, cy, r, lane);
+            double d = 2.0 * (double)r;
+            if (d <= P.tap_diam && n <= (int64_t)P.tap_max_v) {      // the vertex test is evaluated after the perimeter in the reference but decides alone
+                double per = vs::arc_length(p, n, false);
+                if (per <= P.tap_max_per) { tap = 1; txy = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy)); }
+            }
+            if (!tap && d >= P.min_keep) keep = 1;
+        }
+        if (lane == 0) { is_tap[i] = tap; is_keep[i] = keep; if (tap) tap_xy[i] = txy; }
+    }
 }
 __global__ __launch_bounds__(256) void k_compact_sel(const unsigned* __restrict__ flag, const unsigned* __restrict__ scan, int64_t n, const int64_t* __restrict__ off,
                                                       GatherDesc* __restrict__ d, const int2* __restrict__ tap_xy, int2* __restrict__ taps_out) {
@@ -151,11 +211,12 @@ __global__ __launch_bounds__(256) void k_compact_sel(const unsigned* __restrict_
 }
 
 // ---- paint: exact disc dilation of the vertex set ----
-__global__ __launch_bounds__(256) void k_seed_mark(const int2* __restrict__ pts, int64_t n, u8* __restrict__ seeds, int Hp, int Wp) {
+// occ: one byte per 64x32 block of the padded raster, set when the block holds a seed (lets the row / column passes skip empty regions)
+__global__ __launch_bounds__(256) void k_seed_mark(const int2* __restrict__ pts, int64_t n, u8* __restrict__ seeds, int Hp, int Wp, u8* __restrict__ occ, int occ_w) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int x = pts[i].x + ORIP_PAD, y = pts[i].y + ORIP_PAD;
-    if (x >= 0 && x < Wp && y >= 0 && y < Hp) seeds[(size_t)y * Wp + x] = 1;
+    if (x >= 0 && x < Wp && y >= 0 && y < Hp) { seeds[(size_t)y * Wp + x] = 1; occ[(size_t)(y >> 5) * occ_w + (x >> 6)] = 1; }
 }
 // one wave per padded row: horizontal distance to the nearest seed of the row, capped at 255
 __global__ __launch_bounds__(64) void k_row_hdist(const u8* __restrict__ seeds, u8* __restrict__ hd, int Hp, int Wp) {
@@ -185,20 +246,44 @@ __global__ __launch_bounds__(64) void k_row_hdist(const u8* __restrict__ seeds, 
         if (b) nxt = (c << 6) + __ffsll((long long)b) - 1;
     }
 }
-__global__ __launch_bounds__(256) void k_col_cover(const u8* __restrict__ hd, u8* __restrict__ forb, int H, int W, int Hp, int Wp, int r) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    size_t o = (size_t)y * W + x;
-    if (forb[o]) return;
-    const int r2 = r * r;
-    bool cov = false;
-    for (int dy = -r; dy <= r && !cov; dy++) {
-        int yy = y + dy + ORIP_PAD;
-        if (yy < 0 || yy >= Hp) continue;
-        int h = hd[(size_t)yy * Wp + x + ORIP_PAD];
-        if (h * h + dy * dy <= r2) cov = true;
+// column pass: pixel (x,y) is covered iff some row y+dy (|dy| <= r) has a seed within sqrt(r^2 - dy^2) of column x.  The hd rows a 64x32 tile
+// needs (r above and below) are staged in LDS once; every output then reads its column of the staged tile.
+#define CC_TX 64
+#define CC_TY 32
+#define CC_RMAX 62
+__global__ __launch_bounds__(256) void k_col_cover(const u8* __restrict__ hd, u8* __restrict__ forb, int H, int W, int Hp, int Wp, int r, const u8* __restrict__ occ, int occ_w, int occ_h) {
+    __shared__ u8 T[CC_TY + 2 * CC_RMAX][CC_TX];
+    const int x0 = blockIdx.x * CC_TX, y0 = blockIdx.y * CC_TY;
+    {   // any seed within reach of this tile?  padded block coordinates of the tile: (x0+PAD)/64 = bx+1, rows (y0+PAD-r .. y0+PAD+TY+r)
+        int obx = (x0 + ORIP_PAD) >> 6, oby0 = max(0, (y0 + ORIP_PAD - r) >> 5), oby1 = min(occ_h - 1, (y0 + ORIP_PAD + CC_TY - 1 + r) >> 5);
+        bool any = false;
+        for (int by = oby0; by <= oby1 && !any; by++) for (int bx = max(0, obx - 1); bx <= min(occ_w - 1, obx + 1); bx++) if (occ[(size_t)by * occ_w + bx]) { any = true; break; }
+        if (!any) return;
     }
-    if (cov) forb[o] = 255;
+    const int rows = CC_TY + 2 * r;
+    for (int i = threadIdx.x; i < rows * (CC_TX / 4); i += 256) {
+        int ty = i / (CC_TX / 4), tx4 = (i % (CC_TX / 4)) * 4;
+        int yy = y0 - r + ty + ORIP_PAD;                       // padded row
+        uint32_t v = 0xffffffffu;
+        if (yy >= 0 && yy < Hp) {
+            int xx = x0 + tx4 + ORIP_PAD;
+            if (xx + 3 < Wp && ((Wp & 3) == 0)) v = *reinterpret_cast<const uint32_t*>(hd + (size_t)yy * Wp + xx);
+            else { v = 0; for (int j = 0; j < 4; j++) { int xj = xx + j; uint32_t b = (xj < Wp) ? hd[(size_t)yy * Wp + xj] : 255u; v |= b << (8 * j); } }
+        }
+        *reinterpret_cast<uint32_t*>(&T[ty][tx4]) = v;
+    }
+    __syncthreads();
+    const int r2 = r * r;
+    for (int i = threadIdx.x; i < CC_TX * CC_TY; i += 256) {
+        int tx = i % CC_TX, ty = i / CC_TX;
+        int x = x0 + tx, y = y0 + ty;
+        if (x >= W || y >= H) continue;
+        size_t o = (size_t)y * W + x;
+        if (forb[o]) continue;
+        bool cov = false;
+        for (int dy = -r; dy <= r; dy++) { int h = T[ty + r + dy][tx]; if (h * h + dy * dy <= r2) { cov = true; break; } }
+        if (cov) forb[o] = 255;
+    }
 }
 __global__ __launch_bounds__(256) void k_stamp_discs(const int2* __restrict__ taps, int n, int r, u8* __restrict__ forb, int H, int W) {
     for (int t = blockIdx.x; t < n; t += gridDim.x) {
@@ -250,10 +335,15 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
     HIPC(c, LN(c).canvas.ensure((size_t)W * H + 64));
     u8* forb = LN(c).canvas.as<u8>();
     HIPC(c, hipMemsetAsync(forb, 0, (size_t)W * H, LN(c).stream));
-    HIPC(c, LN(c).vtmp[9].ensure((size_t)Wp * Hp * 2 + 64));
-    u8* seeds = LN(c).vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp;
+    const int occ_w = (Wp + 63) >> 6, occ_h = (Hp + 31) >> 5;
+    HIPC(c, LN(c).vtmp[9].ensure((size_t)Wp * Hp * 2 + (size_t)occ_w * occ_h + 64));
+    u8* seeds = LN(c).vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp; u8* occ = hd + (size_t)Wp * Hp;
+    const bool tdbg = getenv("ORIP_TIME10") != nullptr;
+    auto now = [&]() { hipStreamSynchronize(LN(c).stream); return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (int li = 0; li < n_layers; li++) {
         const int layer = order[li];
+        auto t0 = tdbg ? now() : std::chrono::steady_clock::time_point();
         if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
         DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
         DTaps& Tin = c->taps[ORIP_TAPS_INTRA][layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
@@ -276,6 +366,7 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
                 ORIP_TRY(orip_runs_to_polys(c, spt, sflag, n_slots, cut));
             }
         }
+        auto t1 = tdbg ? now() : t0;
         // ---- 2,3) jumps are the identity; tiny lines -> taps / dropped
         int64_t n_tap_lines = 0;
         keepl.n = 0; keepl.total = 0;
@@ -287,7 +378,7 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
             HIPC(c, LN(c).vtmp[10].ensure((size_t)cut.n * sizeof(PolyFeat) + 64));
             PolyFeat* cfeat = LN(c).vtmp[10].as<PolyFeat>();
             ORIP_TRY(vfeatures(c, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, cut.total, 0, cfeat));
-            hipLaunchKernelGGL(k_tiny_taps10, dim3(cdiv(cut.n + 1, 128)), dim3(128), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, cfeat, is_tap, is_keep, tap_xy);
+            hipLaunchKernelGGL(k_tiny_taps10, dim3((unsigned)std::min<int64_t>(cut.n + 1, 65535)), dim3(64), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, cfeat, is_tap, is_keep, tap_xy);
             ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
             ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));
             unsigned a = 0, b = 0;
@@ -304,15 +395,19 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
         int2* seq = LN(c).vtmp[3].as<int2>(); int2* acc = seq + (n_seq + 1);
         if (Tin.n) HIPC(c, hipMemcpyAsync(seq, Tin.xy.p, (size_t)Tin.n * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         if (n_tap_lines) hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, LN(c).stream, is_tap, tap_scan, cut.n, cut.off.as<int64_t>(), (GatherDesc*)nullptr, tap_xy, seq + Tin.n);
+        auto t2 = tdbg ? now() : t0;
         // ---- 4) reorder
         ORIP_TRY(vreorder(c, keepl, Lout, 10));
+        auto t3 = tdbg ? now() : t0;
         // ---- 5) paint lines (exact disc dilation of all vertices)
         if (Lout.total > 0) {
             HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, LN(c).stream));
-            hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp);
+            HIPC(c, hipMemsetAsync(occ, 0, (size_t)occ_w * occ_h, LN(c).stream));
+            hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp, occ, occ_w);
             { ProfScope ps(c, "k_row_hdist"); hipLaunchKernelGGL(k_row_hdist, dim3(Hp), dim3(64), 0, LN(c).stream, seeds, hd, Hp, Wp); }
-            { ProfScope ps(c, "k_col_cover"); hipLaunchKernelGGL(k_col_cover, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), 0, LN(c).stream, hd, forb, H, W, Hp, Wp, rad_lines); }
+            { ProfScope ps(c, "k_col_cover"); hipLaunchKernelGGL(k_col_cover, dim3(cdiv(W, CC_TX), cdiv(H, CC_TY)), dim3(256), 0, LN(c).stream, hd, forb, H, W, Hp, Wp, rad_lines, occ, occ_w, occ_h); }
         }
+        auto t4 = tdbg ? now() : t0;
         // ---- 6) sequential taps
         Tout.n = 0;
         HIPC(c, Tout.xy.ensure((size_t)std::max<int64_t>(n_seq, 1) * 8 + 64));
@@ -329,6 +424,7 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
         }
         HIPC(c, hipGetLastError());
         HIPC(c, hipStreamSynchronize(LN(c).stream));
+        if (tdbg) { auto t5 = now(); fprintf(stderr, "[time10] layer %d: cut %.2f  tiny/taps %.2f  reorder %.2f  paint %.2f  taps %.2f ms (lines in %lld pts %lld -> out %lld pts %lld)\n", layer, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), (long long)Lin.n, (long long)Lin.total, (long long)Lout.n, (long long)Lout.total); }
     }
     return 0;
 }
