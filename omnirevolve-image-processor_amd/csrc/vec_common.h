@@ -248,6 +248,113 @@ __global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict
         __syncthreads();
     }
 }
+// Grid-pruned variant (same selection rule, same tie-break, n <= 16000 and int16 coordinates): the entry points (start of every
+// polyline, end of every polyline that may be entered reversed) are bucketed into a G x G grid held in LDS next to the end points.
+// A greedy step scans the (2r+1)^2 cells around the cursor, r = 1, 3, 7, ...; it is final as soon as the best squared distance is
+// below the squared gap between the cursor and the nearest unscanned cell (every unscanned entry is at least that far, so it can
+// neither win nor tie), or the window covers the grid.  One barrier per scan; all threads track the cursor redundantly.
+__global__ __launch_bounds__(1024) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
+                                                          int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    short4* P = reinterpret_cast<short4*>(smem);                                   // (sx, sy, ex, ey)
+    unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // G*G + 1 cell starts
+    uint16_t* Eid = reinterpret_cast<uint16_t*>(cst + (G * G + 1));                // entries sorted by cell: idx << 1 | end
+    uint8_t* stt = reinterpret_cast<uint8_t*>(Eid + 2 * (size_t)n);                // bit0 used, bit1 closed (rule07)
+    __shared__ unsigned long long wbest[2][16];
+    __shared__ int red[4][16];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- load + bounding box
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
+    for (int i = tid; i < n; i += 1024) {
+        NNEnds e = ends[i];
+        P[i] = make_short4((short)e.sx, (short)e.sy, (short)e.ex, (short)e.ey);
+        stt[i] = (uint8_t)((i == seed ? 1 : 0) | ((rule07 && e.closed) ? 2 : 0));
+        mnx = min(mnx, min(e.sx, e.ex)); mxx = max(mxx, max(e.sx, e.ex)); mny = min(mny, min(e.sy, e.ey)); mxy = max(mxy, max(e.sy, e.ey));
+    }
+    for (int o = 32; o > 0; o >>= 1) { mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); }
+    if (lane == 0) { red[0][wave] = mnx; red[1][wave] = mny; red[2][wave] = mxx; red[3][wave] = mxy; }
+    for (int i = tid; i <= G * G; i += 1024) cst[i] = 0;
+    __syncthreads();
+    for (int w = 0; w < 16; w++) { mnx = min(mnx, red[0][w]); mny = min(mny, red[1][w]); mxx = max(mxx, red[2][w]); mxy = max(mxy, red[3][w]); }
+    const int ox = mnx, oy = mny;
+    const int cs = max(1, (max(mxx - mnx, mxy - mny) + G) / G);                     // (coord - origin) / cs < G for every end point
+    // ---- counting sort of the entries by cell
+    for (int i = tid; i < n; i += 1024) {
+        short4 e = P[i];
+        atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u);
+        if (!(stt[i] & 2)) atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of G*G counts: 4 consecutive cells per thread (G <= 64)
+        unsigned v[4], s = 0;
+        for (int j = 0; j < 4; j++) { int cidx = tid * 4 + j; v[j] = cidx < G * G ? cst[cidx] : 0u; s += v[j]; }
+        unsigned inc = s;
+        for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned base = 0; for (int w = 0; w < wave; w++) base += wsum[w];
+        unsigned run = base + inc - s;
+        for (int j = 0; j < 4; j++) { int cidx = tid * 4 + j; if (cidx < G * G) cst[cidx] = run; run += v[j]; }
+        if (tid == 1023) cst[G * G] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {        // scatter; cst[c] ends up as the END of cell c, i.e. start(c) = c ? cst[c-1] : 0
+        short4 e = P[i];
+        Eid[atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u)] = (uint16_t)(i << 1);
+        if (!(stt[i] & 2)) Eid[atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u)] = (uint16_t)((i << 1) | 1);
+    }
+    int cx, cy;
+    { short4 e = P[seed]; if (stt[seed] & 2) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; } }
+    if (tid == 0) { order[0] = seed; flips[0] = 0; }
+    __syncthreads();
+    int prev = seed, par = 0;
+    for (int step = 1; step < n; step++) {
+        const int gx = (cx - ox) / cs, gy = (cy - oy) / cs;
+        unsigned long long best = ~0ULL;
+        for (int r = 1;; r = 2 * r + 1) {
+            const int x0 = max(0, gx - r), x1 = min(G - 1, gx + r), y0 = max(0, gy - r), y1 = min(G - 1, gy + r);
+            unsigned long long mine = ~0ULL;
+            for (int row = y0 + wave; row <= y1; row += 16) {
+                const int c0 = row * G + x0, c1 = row * G + x1;
+                const unsigned lo = c0 ? cst[c0 - 1] : 0u, hi = cst[c1];
+                for (unsigned q = lo + lane; q < hi; q += 64) {
+                    const unsigned id = Eid[q]; const int i = (int)(id >> 1);
+                    if ((stt[i] & 1) || i == prev) continue;
+                    short4 e = P[i];
+                    float v = (id & 1) ? nn_d2(e.z, e.w, cx, cy) : nn_d2(e.x, e.y, cx, cy);
+                    unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
+                    if (key < mine) mine = key;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(mine, o, 64); if (t < mine) mine = t; }
+            if (lane == 0) wbest[par][wave] = mine;
+            __syncthreads();
+            unsigned long long b = wbest[par][lane & 15];
+            for (int o = 8; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(b, o, 64); if (t < b) b = t; }
+            par ^= 1;
+            best = b;
+            if (x0 == 0 && y0 == 0 && x1 == G - 1 && y1 == G - 1) break;             // everything scanned
+            if (best != ~0ULL) {
+                long long gap = 0x7fffffff;                                          // distance to the nearest unscanned cell, over the open sides
+                if (x0 > 0) gap = min(gap, (long long)(cx - (ox + x0 * cs)) + 1);
+                if (x1 < G - 1) gap = min(gap, (long long)(ox + (x1 + 1) * cs) - cx);
+                if (y0 > 0) gap = min(gap, (long long)(cy - (oy + y0 * cs)) + 1);
+                if (y1 < G - 1) gap = min(gap, (long long)(oy + (y1 + 1) * cs) - cy);
+                double bd = (double)__uint_as_float((unsigned)(best >> 32));
+                if (bd * (1.0 + 1e-6) < (double)gap * (double)gap) break;
+            }
+        }
+        const int bi = (int)(best & 0xffffffffu);
+        short4 e = P[bi]; const uint8_t f = stt[bi];
+        float ds = nn_d2(e.x, e.y, cx, cy), de = nn_d2(e.z, e.w, cx, cy);
+        const bool cl = (f & 2) != 0;
+        const bool flip = cl ? false : !(ds <= de);
+        if (tid == 0) { stt[bi] = f | 1; order[step] = bi; flips[step] = flip ? 1 : 0; }
+        if (cl || flip) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; }
+        prev = bi;
+    }
+}
 // 1 if every coordinate fits int16 (the LDS variant is then exact)
 __global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
     int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -348,9 +455,19 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     ORIP_TRY(vread(c, hs, d_seed, 2));
     const int seed = hs[0];
     const size_t lds = (size_t)n * 9 + 16;
-    if (n <= 16000 && !hs[1]) {
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    int G = 64; while (G > 8 && (size_t)G * G > (size_t)n) G >>= 1;          // about one polyline per cell or more
+    size_t lds_grid = (size_t)n * 13 + (size_t)(G * G + 1) * 4 + 32;
+    while (G > 8 && lds_grid > 158 * 1024) { G >>= 1; lds_grid = (size_t)n * 13 + (size_t)(G * G + 1) * 4 + 32; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_grid), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr_set = true;
+    }
+    if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {
+        ProfScope ps(c, "k_greedy_nn");
+        hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(1024), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips);
+    } else if (n <= 16000 && !hs[1]) {
         ProfScope ps(c, "k_greedy_nn");
         hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, order, flips);
     } else {

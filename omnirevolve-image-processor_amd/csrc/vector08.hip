@@ -10,6 +10,8 @@
 // Stage B (_post_skeleton_merge, 08:376-469) runs all clusters at once on one padded canvas: clusters are >= 76 px apart
 // in one axis, so per-ROI rasterise / thin / label equals whole-canvas rasterise / thin / label (DESIGN.md "stage 08-B").
 #include "vec_common.h"
+#include <chrono>
+#include <string>
 #define PAD8 64
 
 int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst);
@@ -358,24 +360,33 @@ __global__ __launch_bounds__(256) void k_stamp_groups(const int64_t* __restrict_
         }
     }
 }
-__global__ __launch_bounds__(256) void k_gid_to_mask(const unsigned* __restrict__ gid, u8* __restrict__ m, size_t n) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i < n) m[i] = gid[i] ? 255 : 0;
-}
-// standard-orientation Zhang-Suen sub-iteration (08:349-366)
-__global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __restrict__ d, int H, int W, int sub, int* __restrict__ changed) {
+// mask of the stamped raster + list of the 64x4 tiles that hold foreground (thinning only ever clears pixels, so the other tiles stay empty)
+__global__ __launch_bounds__(256) void k_gid_to_mask(const unsigned* __restrict__ gid, u8* __restrict__ m, int H, int W, unsigned* __restrict__ tiles, unsigned* __restrict__ ntiles) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    size_t o = (size_t)y * W + x;
-    u8 v = s[o];
-    if (v) {
-        auto g = [&](int dy, int dx) -> int { int yy = y + dy, xx = x + dx; return (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) ? 1 : 0; };
-        int P2 = g(-1, 0), P3 = g(-1, 1), P4 = g(0, 1), P5 = g(1, 1), P6 = g(1, 0), P7 = g(1, -1), P8 = g(0, -1), P9 = g(-1, -1);
-        int Bn = P2 + P3 + P4 + P5 + P6 + P7 + P8 + P9;
-        int A = (!P2 && P3) + (!P3 && P4) + (!P4 && P5) + (!P5 && P6) + (!P6 && P7) + (!P7 && P8) + (!P8 && P9) + (!P9 && P2);
-        bool cnd = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0) : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
-        if (A == 1 && Bn >= 2 && Bn <= 6 && cnd) { v = 0; *changed = 1; }
+    int fg = 0;
+    if (x < W && y < H) { size_t o = (size_t)y * W + x; fg = gid[o] ? 1 : 0; m[o] = fg ? 255 : 0; }
+    if (__syncthreads_or(fg) && threadIdx.x == 0) tiles[atomicAdd(ntiles, 1u)] = blockIdx.y * gridDim.x + blockIdx.x;
+}
+// standard-orientation Zhang-Suen sub-iteration (08:349-366) over the listed tiles
+__global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __restrict__ d, int H, int W, int sub, int* __restrict__ changed,
+                                                 const unsigned* __restrict__ tiles, const unsigned* __restrict__ ntiles, int gx) {
+    const unsigned nt = *ntiles;
+    for (unsigned ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+        const unsigned t = tiles[ti];
+        int x = (int)(t % gx) * 64 + (threadIdx.x & 63), y = (int)(t / gx) * 4 + (threadIdx.x >> 6);
+        if (x >= W || y >= H) continue;
+        size_t o = (size_t)y * W + x;
+        u8 v = s[o];
+        if (v) {
+            auto g = [&](int dy, int dx) -> int { int yy = y + dy, xx = x + dx; return (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) ? 1 : 0; };
+            int P2 = g(-1, 0), P3 = g(-1, 1), P4 = g(0, 1), P5 = g(1, 1), P6 = g(1, 0), P7 = g(1, -1), P8 = g(0, -1), P9 = g(-1, -1);
+            int Bn = P2 + P3 + P4 + P5 + P6 + P7 + P8 + P9;
+            int A = (!P2 && P3) + (!P3 && P4) + (!P4 && P5) + (!P5 && P6) + (!P6 && P7) + (!P7 && P8) + (!P8 && P9) + (!P9 && P2);
+            bool cnd = sub == 0 ? (P2 * P4 * P6 == 0 && P4 * P6 * P8 == 0) : (P2 * P4 * P8 == 0 && P2 * P6 * P8 == 0);
+            if (A == 1 && Bn >= 2 && Bn <= 6 && cnd) { v = 0; *changed = 1; }
+        }
+        d[o] = v ? 255 : 0;
     }
-    d[o] = v ? 255 : 0;
 }
 // plain (linear id) union-find CCL on the padded raster
 __global__ __launch_bounds__(256) void k_ccl2_init(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
@@ -429,14 +440,37 @@ __global__ __launch_bounds__(256) void k_comp_starts2(const unsigned* __restrict
     if (i < m && head[i]) cs[hs[i]] = (unsigned)i;
 }
 // anchors: nearest skeleton pixel of the group to a0 / a1 (first in raster order on ties, 08:428-432)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o, 64); if (t < v) v = t; }
+    return v;
+}
 __global__ __launch_bounds__(256) void k_nearest_anchor(const unsigned* __restrict__ lin, int64_t m, const unsigned* __restrict__ gid, int Wp, GroupInfo* __restrict__ g) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i >= m) return;
-    unsigned p = lin[i]; int x = (int)(p % Wp) - PAD8, y = (int)(p / Wp) - PAD8;
-    GroupInfo* G = g + (gid[p] - 1);
-    long long d0 = (long long)(y - G->a0y) * (y - G->a0y) + (long long)(x - G->a0x) * (x - G->a0x);
-    long long d1 = (long long)(y - G->a1y) * (y - G->a1y) + (long long)(x - G->a1x) * (x - G->a1x);
-    atomicMin(&G->near0, ((unsigned long long)d0 << 27) | p);
-    atomicMin(&G->near1, ((unsigned long long)d1 << 27) | p);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < m;
+    unsigned grp = 0; unsigned long long k0 = ~0ULL, k1 = ~0ULL;
+    if (valid) {
+        unsigned p = lin[i]; int x = (int)(p % Wp) - PAD8, y = (int)(p / Wp) - PAD8;
+        grp = gid[p] - 1;
+        const GroupInfo* G = g + grp;
+        long long d0 = (long long)(y - G->a0y) * (y - G->a0y) + (long long)(x - G->a0x) * (x - G->a0x);
+        long long d1 = (long long)(y - G->a1y) * (y - G->a1y) + (long long)(x - G->a1x) * (x - G->a1x);
+        k0 = ((unsigned long long)d0 << 27) | p; k1 = ((unsigned long long)d1 << 27) | p;
+    }
+    // pixels next to each other in raster order mostly share their group: one atomic per (wave, group) instead of one per pixel
+    unsigned long long rem = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (rem) {
+        int L = __ffsll((long long)rem) - 1;
+        unsigned gL = (unsigned)__shfl((int)grp, L, 64);
+        bool same = valid && grp == gL;
+        unsigned long long m0 = wave_min_u64(same ? k0 : ~0ULL), m1 = wave_min_u64(same ? k1 : ~0ULL);
+        if (lane == L) {       // the minima only ever decrease: a stale read can only let a useless atomic through, never drop a winner
+            GroupInfo* G = g + gL;
+            if (m0 < *(volatile unsigned long long*)&G->near0) atomicMin(&G->near0, m0);
+            if (m1 < *(volatile unsigned long long*)&G->near1) atomicMin(&G->near1, m1);
+        }
+        rem &= ~__ballot(same);
+    }
 }
 // per component: sort key (group rank, ROI-relative block-raster key of its first block)
 __global__ __launch_bounds__(128) void k_comp_keys(const unsigned* __restrict__ cs, unsigned nc, const unsigned* __restrict__ lin, const unsigned* __restrict__ gid, int Wp,
@@ -457,128 +491,244 @@ __global__ __launch_bounds__(128) void k_comp_keys(const unsigned* __restrict__ 
 __device__ const int OFY[8] = {-1, -1, -1, 0, 1, 1, 1, 0};     // _OFFS (dy,dx), 08:252
 __device__ const int OFX[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
 
-struct BfsArrs { const u8* sk; unsigned* seen; int* prev; int* queue; int Wp, Hp; };
-// BFS from src; returns the last dequeued pixel; stops early at goal (goal < 0: full sweep).  stamp identifies this run.
-__device__ int bfs_run(const BfsArrs& B, int* que, int src, int goal, unsigned stamp) {
-    int head = 0, tail = 0; que[tail++] = src; B.seen[src] = stamp; B.prev[src] = -1;
-    int last = src;
-    while (head < tail) {
-        int cpx = que[head++]; last = cpx;
-        if (cpx == goal) break;
-        int y = cpx / B.Wp, x = cpx % B.Wp;
-        for (int k = 0; k < 8; k++) {
-            int ny = y + OFY[k], nx = x + OFX[k];
-            if (ny < 0 || ny >= B.Hp || nx < 0 || nx >= B.Wp) continue;
-            int j = ny * B.Wp + nx;
-            if (!B.sk[j] || B.seen[j] == stamp) continue;
-            B.seen[j] = stamp; B.prev[j] = cpx; que[tail++] = j;
-        }
-    }
-    return last;
+// ---- _component_best_path (08:295-317) + resample + RDP (08:444-463), one wavefront per skeleton component ----
+// Components are contiguous ranges [cs[c], cs[c+1]) of the raster-ordered pixel list `lin`; a pixel's position in that list is its
+// compact id (cid canvas), its index inside the range its local id.  nbr[q*8+k] = compact id of the k-th _OFFS neighbour (or ~0).
+// The BFS keeps the reference's FIFO order exactly: the queue is consumed eight nodes (64 (node, direction) pairs) at a time, a pixel
+// reached by several pairs of one chunk goes to the lowest pair, and winners are appended in pair order.
+__global__ __launch_bounds__(256) void k_cid_fill(const unsigned* __restrict__ lin, unsigned m, unsigned* __restrict__ cid) {
+    unsigned q = blockIdx.x * 256 + threadIdx.x; if (q < m) cid[lin[q]] = q;
 }
-// _component_best_path (08:295-317) + resample(6) + RDP (08:444-463); one lane per component, in output order
-__global__ __launch_bounds__(64) void k_comp_paths(const unsigned* __restrict__ corder, unsigned nc, const unsigned* __restrict__ cs, const unsigned* __restrict__ keys,
-                                                    const unsigned* __restrict__ lin, const unsigned* __restrict__ gid, const GroupInfo* __restrict__ g, BfsArrs B,
-                                                    int min_len, double step, float eps, float2* __restrict__ fbuf, int2* __restrict__ stack, uint8_t* __restrict__ keepb,
-                                                    int2* __restrict__ outpts, unsigned* __restrict__ outcnt) {
-    unsigned oi = blockIdx.x * 64 + threadIdx.x; if (oi >= nc) return;
-    unsigned c = corder[oi];
-    unsigned b = cs[c], e = cs[c + 1]; int size = (int)(e - b);
-    int root = (int)keys[b];
-    const GroupInfo* G = g + (gid[lin[b]] - 1);
-    int* que = B.queue + b; int* path = B.queue + b;    // the queue segment is reused for the final path
+__global__ __launch_bounds__(256) void k_nbr_build(const unsigned* __restrict__ lin, unsigned m, const u8* __restrict__ sk, const unsigned* __restrict__ cid, int Wp, int Hp, unsigned* __restrict__ nbr) {
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; if (t >= (size_t)m * 8) return;
+    unsigned q = (unsigned)(t >> 3); int k = (int)(t & 7);
+    unsigned p = lin[q]; int y = (int)(p / Wp) + OFY[k], x = (int)(p % Wp) + OFX[k];
+    unsigned v = ~0u;
+    if (y >= 0 && y < Hp && x >= 0 && x < Wp) { size_t j = (size_t)y * Wp + x; if (sk[j]) v = cid[j]; }
+    nbr[t] = v;
+}
+// class lists: 0 = fits the small LDS layout, 1 = the large one, 2 = global scratch
+__global__ __launch_bounds__(256) void k_comp_classes(const unsigned* __restrict__ corder, unsigned nc, const unsigned* __restrict__ cs, unsigned cap0, unsigned cap1, int need,
+                                                      unsigned* __restrict__ counts, unsigned* __restrict__ l0, unsigned* __restrict__ l1, unsigned* __restrict__ l2, unsigned* __restrict__ outcnt) {
+    unsigned oi = blockIdx.x * 256 + threadIdx.x; if (oi >= nc) return;
+    unsigned c = corder[oi]; unsigned s = cs[c + 1] - cs[c];
     outcnt[oi] = 0;
-    int a0 = (G->near0 == ~0ULL) ? -1 : (int)(G->near0 & ((1ULL << 27) - 1)), a1 = (G->near1 == ~0ULL) ? -1 : (int)(G->near1 & ((1ULL << 27) - 1));
-    // "comp[a0]" : the anchor pixel belongs to this component.  keys[] holds the root of every listed pixel; look the anchor up through prev-free test:
-    auto in_comp = [&](int p) -> bool { if (p < 0) return false; for (unsigned q = b; q < e; q++) if ((int)lin[q] == p) return true; return false; };
-    bool ha = in_comp(a0), hb = in_comp(a1);
-    (void)root;
-    const int need = max(2, min_len);
-    int plen = 0; int pu = -1, pv = -1;
-    unsigned stamp = 4u * c + 1u;
-    if (ha && hb) {
-        if (a0 == a1) { plen = 1; }
-        else {
-            bfs_run(B, que, a0, a1, stamp);
-            if (B.seen[a1] == stamp) { int cnt = 1, p = a1; while (p != a0) { p = B.prev[p]; cnt++; } plen = cnt; pu = a0; pv = a1; }
+    if ((int)s < need) return;                              // a path cannot be longer than its component
+    if (s <= cap0) l0[atomicAdd(&counts[0], 1u)] = oi;
+    else if (s <= cap1) l1[atomicAdd(&counts[1], 1u)] = oi;
+    else l2[atomicAdd(&counts[2], 1u)] = oi;
+}
+
+template <bool LDSV> struct CompWork;
+template <> struct CompWork<true> {
+    typedef uint16_t Id; typedef ushort2 Stk;
+    static constexpr unsigned NONE = 0xffffu;
+    Id* nb; Id* prev; Id* que; float* cum; u8* seen; float2* P; Stk* stk; u8* keep;
+    __device__ __forceinline__ unsigned nbr_of(unsigned u, int k) const { return nb[u * 8 + k]; }
+};
+template <> struct CompWork<false> {
+    typedef uint32_t Id; typedef int2 Stk;
+    static constexpr unsigned NONE = 0xffffffffu;
+    const unsigned* nbr; unsigned b;
+    Id* prev; Id* que; float* cum; u8* seen; float2* P; Stk* stk; u8* keep;
+    __device__ __forceinline__ unsigned nbr_of(unsigned u, int k) const { unsigned v = nbr[(size_t)(b + u) * 8 + k]; return v == ~0u ? NONE : v - b; }
+};
+// FIFO BFS from src over local ids; stops when goal is dequeued (goal == NONE: full sweep).  Returns the last dequeued node.
+template <class WK> __device__ unsigned bfs_wave(WK& w, unsigned src, unsigned goal, u8 stamp, int lane) {
+    if (lane == 0) { w.que[0] = (typename WK::Id)src; w.seen[src] = stamp; w.prev[src] = (typename WK::Id)WK::NONE; }
+    __syncthreads();
+    unsigned head = 0, tail = 1;
+    const int slot = lane >> 3, dir = lane & 7;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (head < tail) {
+        unsigned nn = min(8u, tail - head);
+        unsigned u = (unsigned)slot < nn ? (unsigned)w.que[head + slot] : WK::NONE;
+        bool hit = false;
+        if (goal != WK::NONE) {
+            unsigned long long gm = __ballot((unsigned)slot < nn && u == goal);
+            if (gm) { nn = (unsigned)((__ffsll((long long)gm) - 1) >> 3); hit = true; }
         }
-        if (plen < need) plen = 0;
+        bool act = (unsigned)slot < nn;
+        unsigned v = act ? w.nbr_of(u, dir) : WK::NONE;
+        bool nw = act && v != WK::NONE && w.seen[v] != stamp;
+        unsigned long long cand = __ballot(nw), win = 0;
+        while (cand) {
+            int L = __ffsll((long long)cand) - 1;
+            unsigned vL = (unsigned)__shfl((int)v, L, 64);
+            unsigned long long dup = __ballot(nw && v == vL);
+            win |= 1ull << L; cand &= ~dup;
+        }
+        if ((win >> lane) & 1ull) {
+            unsigned pos = tail + (unsigned)__popcll(win & lt);
+            w.que[pos] = (typename WK::Id)v; w.seen[v] = stamp; w.prev[v] = (typename WK::Id)u;
+        }
+        tail += (unsigned)__popcll(win);
+        head += nn;
+        __syncthreads();
+        if (hit) return goal;
     }
+    return (unsigned)w.que[tail - 1];
+}
+
+template <bool LDSV>
+__device__ void comp_path_wave(CompWork<LDSV>& w, unsigned oi, unsigned b, unsigned S, unsigned a0c, unsigned a1c, const unsigned* __restrict__ lin, int Wp,
+                               int min_len, double step, float eps, unsigned pcap, int2* __restrict__ outpts, unsigned* __restrict__ outcnt, int lane) {
+    typedef CompWork<LDSV> WK;
+    const unsigned NONE = WK::NONE;
+    const unsigned e = b + S;
+    const bool ha = a0c >= b && a0c < e, hb = a1c >= b && a1c < e;       // "comp[a0]" (08:300): the anchor pixel lies in this component
+    const unsigned a0 = a0c - b, a1 = a1c - b;
+    const int need = max(2, min_len);
+    int plen = 0; unsigned pv = NONE;
+    if (ha && hb) {
+        if (a0 == a1) plen = 1;
+        else {
+            bfs_wave(w, a0, a1, 1, lane);
+            if (w.seen[a1] == 1) pv = a1;
+        }
+    }
+    // length of the prev-chain ending in pv, written backwards into the tail of the queue buffer (which the path then occupies)
+    auto backtrack = [&](unsigned endn) -> int {
+        int cnt = 0;
+        if (lane == 0) { unsigned p = endn; unsigned pos = S; while (p != NONE) { w.que[--pos] = (typename WK::Id)p; p = (unsigned)w.prev[p]; cnt++; } }
+        cnt = __shfl(cnt, 0, 64);
+        __syncthreads();
+        return cnt;
+    };
+    if (pv != NONE) { plen = backtrack(pv); }
+    if (plen < need) plen = 0;
     if (plen == 0) {
-        int seed = (int)lin[b];
-        int u = bfs_run(B, que, seed, -1, stamp + 1);
-        int v = bfs_run(B, que, u, -1, stamp + 2);
-        // path = bfs(u, v): prev[] of the last sweep already holds the tree rooted at u (the sweep from u is exactly _bfs_path's search, cut at v)
-        int cnt = 1, p = v; while (p != u) { p = B.prev[p]; cnt++; }
-        plen = cnt; pu = u; pv = v;
-        if (u == v) plen = 1;
+        unsigned u = bfs_wave(w, 0u, NONE, 2, lane);                     // seed = first pixel in raster order (08:306)
+        unsigned v = bfs_wave(w, u, NONE, 3, lane);
+        plen = (u == v) ? 1 : backtrack(v);                              // the sweep from u is _bfs_path's own search, cut at v
         if (plen < need) plen = 0;
     }
     if (plen < 2) return;
-    // materialise path u -> v (backtrack from v)
-    { int p = pv; for (int k = plen - 1; k >= 0; k--) { path[k] = p; p = B.prev[p]; } }
-    (void)pu; (void)size;
-    // float32 absolute coordinates; float32 cumsum; resample to float64 then back to float32 (08:444-452)
-    float2* P = fbuf + b;
-    float total = 0.f;
-    {
-        float px = (float)(path[0] % B.Wp - PAD8), py = (float)(path[0] / B.Wp - PAD8);
-        for (int k = 1; k < plen; k++) {
-            float qx = (float)(path[k] % B.Wp - PAD8), qy = (float)(path[k] / B.Wp - PAD8);
-            float dx = qx - px, dy = qy - py; float s = sqrtf(dx * dx + dy * dy);
-            total = (k == 1) ? s : total + s;
-            px = qx; py = qy;
-        }
-    }
+    const typename WK::Id* path = w.que + (S - plen);
+    auto PX = [&](int k) -> float { return (float)((int)(lin[b + path[k]] % (unsigned)Wp) - PAD8); };
+    auto PY = [&](int k) -> float { return (float)((int)(lin[b + path[k]] / (unsigned)Wp) - PAD8); };
+    // float32 segment lengths in parallel, then the sequential float32 cumsum (08:444-446)
+    for (int k = 1 + lane; k < plen; k += 64) { float dx = PX(k) - PX(k - 1), dy = PY(k) - PY(k - 1); w.cum[k] = sqrtf(dx * dx + dy * dy); }
+    __syncthreads();
+    if (lane == 0) { float acc = w.cum[1]; w.cum[0] = 0.f; for (int k = 2; k < plen; k++) { acc = acc + w.cum[k]; w.cum[k] = acc; } }
+    __syncthreads();
+    const float total = w.cum[plen - 1];
     int m;
-    if ((double)total <= step) { m = plen; for (int k = 0; k < plen; k++) P[k] = make_float2((float)(path[k] % B.Wp - PAD8), (float)(path[k] / B.Wp - PAD8)); }
-    else {
+    if ((double)total <= step) {
+        m = plen;
+        if ((unsigned)m > pcap) return;      // cannot happen: pcap >= step + 2
+        for (int k = lane; k < plen; k += 64) w.P[k] = make_float2(PX(k), PY(k));
+    } else {
         m = (int)ceil((double)total / step);
-        float t0 = 0.0f, t1 = (float)(0.0 + step), delta = t1 - t0;
-        int k = 0; float sk = 0.f;          // s[k]; advance with the same sequential cumsum
-        float ax = (float)(path[0] % B.Wp - PAD8), ay = (float)(path[0] / B.Wp - PAD8);
-        float bx = (float)(path[1] % B.Wp - PAD8), by = (float)(path[1] / B.Wp - PAD8);
-        float dx0 = bx - ax, dy0 = by - ay; float seg = sqrtf(dx0 * dx0 + dy0 * dy0); float sk1 = seg;   // s[1]
-        for (int i = 0; i < m; i++) {
+        if ((unsigned)m > pcap) return;      // cannot happen: pcap >= sqrt(2) S / step + 2
+        const float t0 = 0.0f, t1 = (float)(0.0 + step), delta = t1 - t0;
+        for (int i = lane; i < m; i += 64) {
             float tf = i == 0 ? t0 : (i == 1 ? t1 : t0 + (float)i * delta);
             double t = (double)tf;
-            while (k + 2 < plen && (double)sk1 <= t) {       // searchsorted(right)-1, clipped to plen-2
-                k++; sk = sk1; ax = bx; ay = by;
-                bx = (float)(path[k + 1] % B.Wp - PAD8); by = (float)(path[k + 1] / B.Wp - PAD8);
-                float ddx = bx - ax, ddy = by - ay; float sg = sqrtf(ddx * ddx + ddy * ddy);
-                sk1 = sk + sg;
-            }
-            double u = ((t - (double)sk)) / fmax(1e-6, (double)sk1 - (double)sk);
+            int lo = 0, hi = plen - 2;                                   // k = #{ j in [1, plen-2] : s[j] <= t }  (searchsorted right - 1, clipped)
+            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if ((double)w.cum[mid] <= t) lo = mid; else hi = mid - 1; }
+            int k = lo;
+            double sk = (double)w.cum[k], sk1 = (double)w.cum[k + 1];
+            float ax = PX(k), ay = PY(k), bx = PX(k + 1), by = PY(k + 1);
+            double u = (t - sk) / fmax(1e-6, sk1 - sk);
             double a = 1.0 - u;
-            double X = (double)ax * a + (double)bx * u, Y = (double)ay * a + (double)by * u;
-            P[i] = make_float2((float)X, (float)Y);
+            w.P[i] = make_float2((float)((double)ax * a + (double)bx * u), (float)((double)ay * a + (double)by * u));
         }
     }
     if (m < 2) return;
-    // RDP with an explicit LIFO stack (08:453-462)
-    uint8_t* keep = keepb + b; int2* st = stack + b;
-    for (int i = 0; i < m; i++) keep[i] = 0;
-    keep[0] = keep[m - 1] = 1;
-    int sp = 0; st[sp++] = make_int2(0, m - 1);
+    // RDP, explicit LIFO stack (08:453-462); the farthest point of a span is found 64 points at a time
+    for (int i = lane; i < m; i += 64) w.keep[i] = (i == 0 || i == m - 1) ? 1 : 0;
+    int sp = 0;
+    if (lane == 0) { w.stk[0].x = 0; w.stk[0].y = (decltype(w.stk[0].y))(m - 1); }
+    sp = 1;
+    __syncthreads();
     while (sp > 0) {
-        int2 se = st[--sp]; int s = se.x, en = se.y;
+        --sp;
+        const int s = (int)w.stk[sp].x, en = (int)w.stk[sp].y;
+        __syncthreads();
         if (en <= s + 1) continue;
-        float ax = P[s].x, ay = P[s].y, bx = P[en].x, by = P[en].y;
+        float ax = w.P[s].x, ay = w.P[s].y, bx = w.P[en].x, by = w.P[en].y;
         float segx = bx - ax, segy = by - ay, nx = -segy, ny = segx;
         float q = segx * segx + segy * segy;
         double seg_len = (double)sqrtf(q) + 1e-12; float seg_len_f = (float)seg_len;
-        float bestd = -1.f; int bi = 0;
-        for (int i = s + 1; i < en; i++) {
-            float dx = P[i].x - ax, dy = P[i].y - ay;
+        float bestd = -1.f; int bi = 0x7fffffff;
+        for (int i = s + 1 + lane; i < en; i += 64) {
+            float dx = w.P[i].x - ax, dy = w.P[i].y - ay;
             float t0 = dx * nx, t1 = dy * ny;
             float d = fabsf(t0 + t1) / seg_len_f;
             if (d > bestd) { bestd = d; bi = i; }
         }
-        if (bestd > eps) { keep[bi] = 1; st[sp++] = make_int2(s, bi); st[sp++] = make_int2(bi, en); }
+        for (int o = 32; o > 0; o >>= 1) {
+            float od = __shfl_xor(bestd, o, 64); int oi2 = __shfl_xor(bi, o, 64);
+            if (od > bestd || (od == bestd && oi2 < bi)) { bestd = od; bi = oi2; }
+        }
+        if (bestd > eps) {
+            if (lane == 0) {
+                w.keep[bi] = 1;
+                w.stk[sp].x = (decltype(w.stk[0].x))s; w.stk[sp].y = (decltype(w.stk[0].y))bi;
+                w.stk[sp + 1].x = (decltype(w.stk[0].x))bi; w.stk[sp + 1].y = (decltype(w.stk[0].y))en;
+            }
+            sp += 2;
+        }
+        __syncthreads();
     }
     int2* o = outpts + b; unsigned cnt = 0;
-    for (int i = 0; i < m; i++) if (keep[i]) o[cnt++] = make_int2((int)P[i].x, (int)P[i].y);
-    outcnt[oi] = cnt;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        int i = i0 + lane; bool kp = i < m && w.keep[i];
+        unsigned long long bm = __ballot(kp);
+        if (kp) { float2 p = w.P[i]; o[cnt + (unsigned)__popcll(bm & lt)] = make_int2((int)p.x, (int)p.y); }
+        cnt += (unsigned)__popcll(bm);
+    }
+    if (lane == 0) outcnt[oi] = cnt;
+}
+
+struct CompArgs {
+    const unsigned* corder; const unsigned* cs; const unsigned* lin; const unsigned* gid; const GroupInfo* g; const unsigned* cid; const unsigned* nbr;
+    int Wp; int min_len; double step; float eps; int2* outpts; unsigned* outcnt;
+};
+__device__ __forceinline__ void comp_anchors(const CompArgs& A, unsigned b, unsigned& a0c, unsigned& a1c) {
+    const GroupInfo* G = A.g + (A.gid[A.lin[b]] - 1);
+    a0c = (G->near0 == ~0ULL) ? ~0u : A.cid[(unsigned)(G->near0 & ((1ULL << 27) - 1))];
+    a1c = (G->near1 == ~0ULL) ? ~0u : A.cid[(unsigned)(G->near1 & ((1ULL << 27) - 1))];
+}
+// LDS-resident components (cap nodes, pcap resample points per block)
+__global__ __launch_bounds__(64) void k_comp_paths_lds(CompArgs A, const unsigned* __restrict__ list, const unsigned* __restrict__ count, unsigned cap, unsigned pcap) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    CompWork<true> w;
+    w.cum = reinterpret_cast<float*>(smem);
+    w.P = reinterpret_cast<float2*>(w.cum + cap);
+    w.stk = reinterpret_cast<ushort2*>(w.P + pcap);
+    w.nb = reinterpret_cast<uint16_t*>(w.stk + pcap);
+    w.prev = w.nb + (size_t)cap * 8; w.que = w.prev + cap;
+    w.seen = reinterpret_cast<u8*>(w.que + cap); w.keep = w.seen + cap;
+    const int lane = threadIdx.x;
+    const unsigned n = *count;
+    for (unsigned li = blockIdx.x; li < n; li += gridDim.x) {
+        unsigned oi = list[li]; unsigned c = A.corder[oi]; unsigned b = A.cs[c], S = A.cs[c + 1] - b;
+        for (unsigned t = lane; t < S * 8; t += 64) { unsigned v = A.nbr[(size_t)b * 8 + t]; w.nb[t] = v == ~0u ? (uint16_t)0xffffu : (uint16_t)(v - b); }
+        for (unsigned t = lane; t < S; t += 64) w.seen[t] = 0;
+        __syncthreads();
+        unsigned a0c, a1c; comp_anchors(A, b, a0c, a1c);
+        comp_path_wave<true>(w, oi, b, S, a0c, a1c, A.lin, A.Wp, A.min_len, A.step, A.eps, pcap, A.outpts, A.outcnt, lane);
+        __syncthreads();
+    }
+}
+// components too large for LDS: same code over per-pixel scratch in global memory
+struct CompScratch { unsigned* prev; unsigned* que; float* cum; u8* seen; float2* P; int2* stk; u8* keep; };
+__global__ __launch_bounds__(64) void k_comp_paths_glb(CompArgs A, const unsigned* __restrict__ list, const unsigned* __restrict__ count, CompScratch X) {
+    const int lane = threadIdx.x;
+    const unsigned n = *count;
+    for (unsigned li = blockIdx.x; li < n; li += gridDim.x) {
+        unsigned oi = list[li]; unsigned c = A.corder[oi]; unsigned b = A.cs[c], S = A.cs[c + 1] - b;
+        CompWork<false> w; w.nbr = A.nbr; w.b = b;
+        w.prev = X.prev + b; w.que = X.que + b; w.cum = X.cum + b; w.seen = X.seen + b; w.P = X.P + b; w.stk = X.stk + b; w.keep = X.keep + b;
+        for (unsigned t = lane; t < S; t += 64) w.seen[t] = 0;
+        __syncthreads();
+        unsigned a0c, a1c; comp_anchors(A, b, a0c, a1c);
+        comp_path_wave<false>(w, oi, b, S, a0c, a1c, A.lin, A.Wp, A.min_len, A.step, A.eps, S, A.outpts, A.outcnt, lane);
+        __syncthreads();
+    }
 }
 __global__ __launch_bounds__(256) void k_path_desc(const unsigned* __restrict__ corder, const unsigned* __restrict__ cs, const unsigned* __restrict__ outcnt, const unsigned* __restrict__ flag,
                                                     const unsigned* __restrict__ scan, unsigned nc, GatherDesc* __restrict__ d) {
@@ -647,40 +797,55 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     struct Ref { DPolys& p; }; Ref kept0{LN(c).tp[0]}, cleaned{LN(c).tp[1]}, lines2{LN(c).tp[2]}, merged{LN(c).tp[3]};
     for (Ref* r : {&kept0, &cleaned, &lines2, &merged}) { r->p.n = 0; r->p.total = 0; }
     int64_t nt0 = 0, nt2 = 0;
+    const bool tdbg = getenv("ORIP_TIME08") != nullptr;      // debug: per-phase wall times of this layer (adds stream syncs)
+    std::string tlog; auto tprev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* name) {
+        if (!tdbg) return;
+        hipStreamSynchronize(LN(c).stream);
+        auto t = std::chrono::steady_clock::now(); char b[64];
+        snprintf(b, sizeof b, " %s %.2f", name, std::chrono::duration<double, std::milli>(t - tprev).count()); tlog += b; tprev = t;
+    };
     // ---- A0
     ORIP_TRY(split_small(c, S, P, kept0.p, TOUT.xy, 0, &nt0));
     const int64_t nk = kept0.p.n;
+    tick("split");
     if (nk > 0) {
         if (kept0.p.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
         // ---- A1: order by perimeter, descending, stable
         HIPC(c, LN(c).vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
         PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
         ORIP_TRY(vfeatures(c, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, kept0.p.total, 1, feat));
+        tick("feat");
         HIPC(c, LN(c).vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
         float* kin = LN(c).vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
         unsigned* mr = ord + nk; unsigned* sbase = mr + (nk + 1); RsInfo* info = (RsInfo*)(sbase + (nk + 1) + 2);   // (6 nk + 4) dwords: 8-byte aligned
         hipLaunchKernelGGL(k_fill_per, dim3(cdiv(nk, 256)), dim3(256), 0, LN(c).stream, feat, nk, kin, vin);
         ORIP_TRY((vsort_pairs<float, unsigned>(c, kin, kout, vin, ord, (size_t)nk, 0, 32, true)));
+        tick("A0-1");
         // ---- A2: resample
         HIPC(c, LN(c).vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
         float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
         if (kept0.p.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
+        tick("cumlen");
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
         unsigned MS = 0;
         ORIP_TRY(vread(c, &MS, sbase + nk));
         if (MS > 0) {
             if (MS > 0x7ffffff0u) ORIP_FAIL(c, "too many samples");
+            if (tdbg) { char b[48]; snprintf(b, sizeof b, " [MS %u]", MS); tlog += b; }
             HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
             SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.dprev = A.sy + MS; A.xi = (int*)(A.dprev + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
             unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
             { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
+            tick("samples");
             // ---- A3
             { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop); }
             hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, capprev);
+            tick("tail");
             // ---- A4: de-duplicated capsules -> min-sequence canvas
             HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
             unsigned* firstseq = LN(c).canvas.as<unsigned>();
@@ -692,6 +857,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, LN(c).stream));
             { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1); }
             { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
+            tick("caps");
             // ---- A5: (polyline, cell) buckets in pop order
             HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
             unsigned long long* ckin = LN(c).vtmp[5].as<unsigned long long>(); unsigned long long* ckout = ckin + MS; unsigned* cvin = (unsigned*)(ckout + MS); unsigned* cvout = cvin + MS;
@@ -699,15 +865,19 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, MS, inv, ckin, cvin);
             int rbits = 1; while ((1ll << rbits) < nk + 1) rbits++;
             { ProfScope ps(c, "sort_cells"); ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cvin, cvout, (size_t)MS, 0, 32 + rbits))); }
+            tick("cells");
             // ---- A6
             { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, inv, P.col_rad * P.col_rad, ckout, cvout, firstseq, W, spt, sflag); }
             HIPC(c, hipGetLastError());
+            tick("accept");
             ORIP_TRY(orip_runs_to_polys(c, spt, sflag, MS, cleaned.p));
+            tick("runs");
         }
         // ---- A7
         ORIP_TRY(split_small(c, cleaned.p, P, lines2.p, TOUT.xy, nt0, &nt2));
     }
     TOUT.n = nt0 + nt2;
+    tick("A7");
     // ---- B
     DPolys* fin = &lines2.p;
     const int64_t n2 = lines2.p.n;
@@ -726,29 +896,37 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         hipLaunchKernelGGL(k_group_accum, dim3(cdiv(n2 + 1, 256)), dim3(256), 0, LN(c).stream, f2, (int)n2, exp, par, grp, is_root);
         ORIP_TRY(vscan_excl<unsigned>(c, is_root, root_scan, (size_t)n2 + 1));
         hipLaunchKernelGGL(k_group_finish, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, f2, (int)n2, is_root, root_scan, grp);
+        tick("groups");
         // raster
         HIPC(c, LN(c).canvas.ensure(Np * 4 + 64));
         unsigned* gid = LN(c).canvas.as<unsigned>();
         HIPC(c, hipMemsetAsync(gid, 0, Np * 4, LN(c).stream));
         { ProfScope ps(c, "k_stamp_groups"); hipLaunchKernelGGL(k_stamp_groups, dim3(8192), dim3(256), 0, LN(c).stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, par, rad, gid, Wp, Hp); }
-        HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + 64));
-        u8* skA = LN(c).vtmp[9].as<u8>(); u8* skB = skA + Np;
-        hipLaunchKernelGGL(k_gid_to_mask, dim3(cdiv(Np, 256)), dim3(256), 0, LN(c).stream, gid, skA, Np);
-        int* d_changed = LN(c).flags.as<int>() + 48;
         dim3 g2(cdiv(Wp, 64), cdiv(Hp, 4)), blk(256);
+        const size_t ntile_max = (size_t)g2.x * g2.y;
+        HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + ntile_max * 4 + 128));
+        u8* skA = LN(c).vtmp[9].as<u8>(); u8* skB = skA + Np; unsigned* tiles = (unsigned*)(skB + ((Np + 15) & ~(size_t)15));
+        int* d_changed = LN(c).flags.as<int>() + 48; unsigned* d_ntiles = LN(c).flags.as<unsigned>() + 52;
+        HIPC(c, hipMemsetAsync(d_ntiles, 0, 4, LN(c).stream));
+        HIPC(c, hipMemsetAsync(skB, 0, Np, LN(c).stream));
+        hipLaunchKernelGGL(k_gid_to_mask, g2, blk, 0, LN(c).stream, gid, skA, Hp, Wp, tiles, d_ntiles);
+        tick("raster");
+        const dim3 gz((unsigned)std::min<size_t>(ntile_max, 16384));
         for (int it = 0; it < 48; it++) {
             HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
-            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, LN(c).stream, skA, skB, Hp, Wp, 0, d_changed); }
-            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, g2, blk, 0, LN(c).stream, skB, skA, Hp, Wp, 1, d_changed); }
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, gz, blk, 0, LN(c).stream, skA, skB, Hp, Wp, 0, d_changed, tiles, d_ntiles, (int)g2.x); }
+            { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, gz, blk, 0, LN(c).stream, skB, skA, Hp, Wp, 1, d_changed, tiles, d_ntiles, (int)g2.x); }
             int ch = 0; ORIP_TRY(vread(c, &ch, d_changed));
             if (!ch) break;
         }
+        tick("thin");
         // components
         HIPC(c, LN(c).vtmp[10].ensure(Np * 4 + 64));
         int* L2 = LN(c).vtmp[10].as<int>();
         hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp);
         { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp); }
         hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, L2, (int)Np);
+        tick("c:ccl");
         const int nblk = cdiv((int64_t)Np, 1024);
         HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
         unsigned* bc = LN(c).vtmp[0].as<unsigned>(); unsigned* bo = bc + (nblk + 1);
@@ -771,30 +949,70 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             unsigned* cs = (unsigned*)(ckout + (NC + 1)); unsigned* cidx = cs + (NC + 2); unsigned* corder = cidx + (NC + 1); unsigned* outcnt = corder + (NC + 1);
             unsigned* oflag = outcnt + (NC + 1); unsigned* oscan = oflag + (NC + 1); GatherDesc* pd = (GatherDesc*)(oscan + (NC + 1) + ((6 * (NC + 1) + 1) & 1) + 2);
             hipLaunchKernelGGL(k_comp_starts2, dim3(cdiv(M, 256)), blk, 0, LN(c).stream, head, hs, (int64_t)M, cs, NC);
+            tick("c:sort");
             hipLaunchKernelGGL(k_nearest_anchor, dim3(cdiv(M, 256)), blk, 0, LN(c).stream, lin, (int64_t)M, gid, Wp, grp);
+            tick("c:anchor");
             hipLaunchKernelGGL(k_comp_keys, dim3(cdiv(NC, 128)), dim3(128), 0, LN(c).stream, cs, NC, lin, gid, Wp, grp, ckin, cidx);
             ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cidx, corder, (size_t)NC, 0, 64)));
+            tick("comps");
             // per-component path, resample, RDP
-            HIPC(c, LN(c).vtmp[5].ensure(Np * 8 + (size_t)M * (4 + 8 + 8 + 1 + 8) + 256));
-            BfsArrs B; B.sk = skA; B.seen = LN(c).vtmp[5].as<unsigned>(); B.prev = (int*)(B.seen + Np); B.queue = B.prev + Np; B.Wp = Wp; B.Hp = Hp;
-            float2* fbuf = (float2*)(B.queue + M + (M & 1)); int2* stk = (int2*)(fbuf + M); int2* outpts = stk + M; uint8_t* keepb = (uint8_t*)(outpts + M);
-            HIPC(c, hipMemsetAsync(B.seen, 0, Np * 4, LN(c).stream));
-            { ProfScope ps(c, "k_comp_paths"); hipLaunchKernelGGL(k_comp_paths, dim3(cdiv(NC, 64)), dim3(64), 0, LN(c).stream, corder, NC, cs, keys, lin, gid, grp, B, P.post_minlen, P.post_step, (float)P.post_eps, fbuf, stk, keepb, outpts, outcnt); }
-            hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, LN(c).stream, outcnt, NC, oflag);
-            ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
-            unsigned NP = 0; ORIP_TRY(vread(c, &NP, oscan + NC));
-            merged.p.n = 0; merged.p.total = 0;
-            HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream));
-            if (NP) {
-                hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, cs, outcnt, oflag, oscan, NC, pd);
-                ORIP_TRY(vgather(c, pd, NP, reinterpret_cast<const int32_t*>(outpts), merged.p));
+            {
+                const double stp = P.post_step;
+                if (!(stp >= 1.0)) ORIP_FAIL(c, "postmerge_resample_step must be >= 1");
+                const double ratio = std::min(1.0, 1.41422 / stp);          // resample points per component pixel
+                auto pcap_of = [&](unsigned cap) { return (unsigned)(cap * ratio) + (unsigned)stp + 4u; };
+                auto cap_of = [&](size_t budget) {                             // bytes: 25/node + 13/resample point
+                    unsigned cap = (unsigned)((budget - 13.0 * (stp + 4.0) - 64.0) / (25.0 + 13.0 * ratio));
+                    return std::min(cap, 65000u) & ~7u;
+                };
+                const size_t lds0 = 32 * 1024, lds1 = 160 * 1024;
+                unsigned cap0 = cap_of(lds0), cap1 = cap_of(lds1);
+                if (const char* ov = getenv("ORIP_COMP_CAPS")) {          // test hook: force components into the larger classes
+                    unsigned a = 0, b2 = 0; if (sscanf(ov, "%u,%u", &a, &b2) == 2 && a >= 8 && a <= b2) { cap0 = std::min(cap0, a & ~7u); cap1 = std::min(cap1, b2 & ~7u); }
+                }
+                auto lds_bytes = [&](unsigned cap) { return (size_t)cap * 25 + (size_t)pcap_of(cap) * 13 + 16; };
+                // scratch: cid canvas (reuses the BFS canvas), nbr, class lists, global-class work arrays
+                HIPC(c, LN(c).vtmp[5].ensure(Np * 4 + (size_t)M * (32 + 4 + 4 + 4 + 8 + 8 + 1 + 1 + 8) + (size_t)(NC + 1) * 12 + 1024));
+                unsigned char* bump = LN(c).vtmp[5].as<unsigned char>();
+                auto take = [&](size_t bytes) { unsigned char* r = bump; bump += (bytes + 15) & ~(size_t)15; return r; };
+                unsigned* cid = (unsigned*)take(Np * 4); unsigned* nbr = (unsigned*)take((size_t)M * 32);
+                CompScratch X; X.prev = (unsigned*)take((size_t)M * 4); X.que = (unsigned*)take((size_t)M * 4); X.cum = (float*)take((size_t)M * 4);
+                X.P = (float2*)take((size_t)M * 8); X.stk = (int2*)take((size_t)M * 8); int2* outpts = (int2*)take((size_t)M * 8);
+                unsigned* l0 = (unsigned*)take((size_t)(NC + 1) * 4); unsigned* l1 = (unsigned*)take((size_t)(NC + 1) * 4); unsigned* l2 = (unsigned*)take((size_t)(NC + 1) * 4);
+                X.seen = (u8*)take(M); X.keep = (u8*)take(M);
+                unsigned* counts = LN(c).flags.as<unsigned>() + 56;
+                HIPC(c, hipMemsetAsync(counts, 0, 12, LN(c).stream));
+                hipLaunchKernelGGL(k_cid_fill, dim3(cdiv(M, 256)), blk, 0, LN(c).stream, lin, M, cid);
+                hipLaunchKernelGGL(k_nbr_build, dim3((unsigned)cdiv((int64_t)M * 8, 256)), blk, 0, LN(c).stream, lin, M, skA, cid, Wp, Hp, nbr);
+                hipLaunchKernelGGL(k_comp_classes, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, NC, cs, cap0, cap1, std::max(2, P.post_minlen), counts, l0, l1, l2, outcnt);
+                CompArgs A; A.corder = corder; A.cs = cs; A.lin = lin; A.gid = gid; A.g = grp; A.cid = cid; A.nbr = nbr; A.Wp = Wp; A.min_len = P.post_minlen; A.step = stp;
+                A.eps = (float)P.post_eps; A.outpts = outpts; A.outcnt = outcnt;
+                static bool attr_set = false;
+                if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_paths_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); attr_set = true; }
+                ProfScope ps(c, "k_comp_paths");
+                hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 8192u)), dim3(64), lds_bytes(cap0), LN(c).stream, A, l0, counts + 0, cap0, pcap_of(cap0));
+                hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 1024u)), dim3(64), lds_bytes(cap1), LN(c).stream, A, l1, counts + 1, cap1, pcap_of(cap1));
+                hipLaunchKernelGGL(k_comp_paths_glb, dim3(std::min(NC, 1024u)), dim3(64), 0, LN(c).stream, A, l2, counts + 2, X);
+                tick("paths");
+                hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, LN(c).stream, outcnt, NC, oflag);
+                ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
+                unsigned NP = 0; ORIP_TRY(vread(c, &NP, oscan + NC));
+                merged.p.n = 0; merged.p.total = 0;
+                HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream));
+                if (NP) {
+                    hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, cs, outcnt, oflag, oscan, NC, pd);
+                    ORIP_TRY(vgather(c, pd, NP, reinterpret_cast<const int32_t*>(outpts), merged.p));
+                }
             }
         } else { merged.p.n = 0; merged.p.total = 0; HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream)); }
         HIPC(c, hipGetLastError());
         fin = &merged.p;
     }
+    tick("gather");
     // ---- C
     ORIP_TRY(vreorder(c, *fin, OUT, 8));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
+    tick("reorder");
+    if (tdbg) fprintf(stderr, "[time08] layer %d (in %lld polys %lld pts, kept %lld pts, cleaned %lld/%lld, lines2 %lld/%lld):%s\n", layer, (long long)S.n, (long long)S.total, (long long)kept0.p.total, (long long)cleaned.p.n, (long long)cleaned.p.total, (long long)lines2.p.n, (long long)lines2.p.total, tlog.c_str());
     return 0;
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 from . import lib as _l
@@ -193,7 +195,7 @@ def for_each_layer(fn, layers):
     kernels of different layers overlap on the GPU (the reference loops over layers serially: 05:114, 07:99, 08:561, 12:200)."""
     global _pool
     layers = list(layers)
-    if len(layers) <= 1:
+    if len(layers) <= 1 or os.environ.get("ORIP_SERIAL_LAYERS"):      # the switch is a profiling aid: kernels of one layer at a time
         return [fn(l) for l in layers]
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor

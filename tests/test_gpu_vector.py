@@ -65,6 +65,24 @@ def test_stage07_random_vs_oracle(dev, seed):
     assert same_polys(S.sort_contours(polys, dev), O.sort07(polys))
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_stage07_grid_search_ties_and_long_jumps(dev, seed):
+    """Thousands of contours on a coarse lattice, in a few dense clusters far apart: equal distances everywhere (index
+    tie-break) and exhausted neighbourhoods (the grid search has to widen to the whole list)."""
+    from orip import stages as S
+    rng = np.random.default_rng(40 + seed)
+    polys = []
+    centres = rng.integers(500, 7500, (6, 2))
+    for i in range([3000, 9000][seed]):
+        c = centres[int(rng.integers(0, 6))] if rng.random() < 0.9 else rng.integers(0, 8000, 2)
+        m = int(rng.integers(2, 6))
+        p = (c + rng.integers(-6, 7, (m, 2)) * 25).astype(np.int32)
+        if rng.random() < 0.3 and m > 3:
+            p[-1] = p[0]
+        polys.append(p.reshape(-1, 1, 2))
+    assert same_polys(S.sort_contours(polys, dev), O.sort07(polys))
+
+
 def test_stage10_golden(dev, G):
     from orip import stages as S
     cfgd = json.loads(bytes(G["cfg_json"]).decode()); cfg = _cfgobj(cfgd)
@@ -149,6 +167,30 @@ def test_stage08_random_vs_oracle(dev, seed):
     got_l, got_t = S.dedup_layer(polys, cfg, dev)
     assert got_t == want_t
     assert same_polys(got_l, want_l), (len(got_l), len(want_l))
+
+
+def test_stage08_component_size_classes(dev, monkeypatch):
+    """Stage 08-B keeps small skeleton components in LDS, larger ones in a bigger LDS layout, the rest in global scratch:
+    with the capacities forced down every class is exercised on the same input and must give the same lines."""
+    from orip import stages as S
+    rng = np.random.default_rng(321)
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=8)
+    cfg = _cfgobj(cfgd)
+    W, H = O.canvas_size(cfgd)
+    polys = []
+    for _ in range(80):
+        m = int(rng.integers(2, 120))
+        p = (np.cumsum(rng.integers(-22, 23, (m, 2)), axis=0) + rng.integers(50, min(W, H) - 50, 2)).astype(np.int32)
+        polys.append(p.reshape(-1, 1, 2))
+    want_l, want_t = O.stage08_layer(polys, O.derived08(cfgd))
+    for caps in ["16,64", "8,8", None]:
+        if caps:
+            monkeypatch.setenv("ORIP_COMP_CAPS", caps)
+        else:
+            monkeypatch.delenv("ORIP_COMP_CAPS", raising=False)
+        got_l, got_t = S.dedup_layer(polys, cfg, dev)
+        assert got_t == want_t, caps
+        assert same_polys(got_l, want_l), (caps, len(got_l), len(want_l))
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
