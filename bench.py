@@ -24,6 +24,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per layer lane (see orip/lib.py); before torch / HIP start
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "omnirevolve-image-processor_amd"))
 sys.path.insert(0, ROOT)

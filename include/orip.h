@@ -93,6 +93,10 @@ int orip_set_edges(orip_ctx* ctx, const uint8_t* edges, int K, int H, int W);
 
 /* ---- stage 04: 04_find_contours.py vectorize_layer (04:214-230), all layers in one call ---- */
 int orip_find_contours(orip_ctx* ctx);
+/* The same work split for per-layer pipelines: prepare = the part batched over the layers (thinning 04:35-99, components, walk
+ * schedule); contours_layer = the walks of one layer (04:101-211), callable for different layers from different host threads. */
+int orip_contours_prepare(orip_ctx* ctx);
+int orip_contours_layer(orip_ctx* ctx, int layer);
 int orip_get_skeleton(orip_ctx* ctx, int layer, uint8_t* skel_out); /* thinning_zhangsuen output (04:35-99) */
 
 /* ---- polyline-list / tap-list slots ---- */
@@ -112,6 +116,9 @@ int orip_sort_contours(orip_ctx* ctx, int layer);
 int orip_dedup_layer(orip_ctx* ctx, int layer, const orip_params08* prm);
 /* ---- stage 10: main (10:212-278): LINES/TAPS_INTRA -> LINES/TAPS_CROSS, layers visited in `order` ---- */
 int orip_dedup_cross(orip_ctx* ctx, const int32_t* order, int n_layers, const orip_params10* prm);
+/* The same loop one layer at a time (10:230-262): begin clears the cumulative raster, then the layers must be passed in `order`. */
+int orip_dedup_cross_begin(orip_ctx* ctx, const orip_params10* prm);
+int orip_dedup_cross_layer(orip_ctx* ctx, int layer);
 /* ---- stage 12: _build_ops_for_layer (12:85-187): LINES/TAPS_CROSS -> ops ----
  * ops are returned as 5 int32 each: (type 0 line / 1 tap, line index into LINES_CROSS, flip, x, y). */
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);

@@ -1,11 +1,15 @@
 // csrc/orip_api.hip -- context life-cycle, slot transfers and profiling hooks of liborip.so.
 #include "orip_ctx.h"
+#include <cstdlib>
 
 thread_local int orip_tls_lane = 0;
 
 extern "C" int orip_create(int device_id, orip_ctx** out) {
     if (!out) return -1;
     *out = nullptr;
+    // one hardware queue per lane where the runtime still accepts it (HIP multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues by
+    // default, and kernels that share a queue run one after the other): only effective when this is the process's first HIP call
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2;   // no GPU: fail loudly, there is no CPU path
     if (device_id < 0 || device_id >= ndev) return -3;
@@ -39,6 +43,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); }
     for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
+    orip_contours_free(c);
     delete c;
 }
 

@@ -70,11 +70,15 @@ struct LaneRes {
 };
 extern thread_local int orip_tls_lane;
 #define LN(c) ((c)->ln[orip_tls_lane])
+#define ORIP_LANE_CROSS (ORIP_MAX_LAYERS + 1)
+void orip_contours_free(orip_ctx* c);
 struct LaneGuard { int prev; explicit LaneGuard(int lane) : prev(orip_tls_lane) { orip_tls_lane = lane; } ~LaneGuard() { orip_tls_lane = prev; } };
 
 struct orip_ctx {
     int device = 0;
-    LaneRes ln[ORIP_MAX_LAYERS + 1];
+    LaneRes ln[ORIP_MAX_LAYERS + 2];      // 0: raster stages; l + 1: layer l; ORIP_LANE_CROSS: stage 10
+    orip_params10 p10{}; bool p10_ready = false;   // stage 10 between orip_dedup_cross_begin and the per-layer calls
+    void* prep04 = nullptr;               // stage-04 state between orip_contours_prepare and orip_contours_layer (raster04.hip)
     std::mutex mu;
     std::string err;
     // image / raster state

@@ -121,11 +121,6 @@ __global__ __launch_bounds__(256) void k_gather_head_layers(const unsigned* __re
     unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i < nc) out[i] = keys[cs[i]] >> 26;
 }
-__global__ __launch_bounds__(256) void k_clear_visited(u8* __restrict__ st, const unsigned* __restrict__ keys, const unsigned* __restrict__ lin, int64_t m, int64_t plane) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    st[plane * (keys[i] >> 26) + lin[i]] &= (u8)~ST_VIS;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Walker.  NEIGH8 order (dx,dy) from 04:12.
@@ -143,22 +138,10 @@ __global__ __launch_bounds__(64) void k_trace(WalkArgs A) {
 __global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, const unsigned* __restrict__ kept_slots, unsigned n_kept) {
     for (unsigned i = blockIdx.x; i < n_kept; i += gridDim.x) write_walk(A, kept_slots[i]);
 }
-__global__ __launch_bounds__(256) void k_comp_sizes(const unsigned* __restrict__ cs, unsigned nc, unsigned* __restrict__ size, unsigned* __restrict__ idx) {
-    unsigned c = blockIdx.x * 256 + threadIdx.x;
-    if (c < nc) { size[c] = cs[c + 1] - cs[c]; idx[c] = c; }
-}
-__global__ __launch_bounds__(256) void k_fill_qidx(const unsigned* __restrict__ keys, const unsigned* __restrict__ lin, int64_t m, int64_t plane, int* __restrict__ qidx) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) qidx[plane * (keys[i] >> 26) + lin[i]] = (int)i;
-}
 __global__ __launch_bounds__(256) void k_winfo_lens(const WalkInfo* __restrict__ wi, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { unsigned l = wi[i].len_kept; lens[i] = l; kept[i] = l ? 1u : 0u; }
     if (i == n) { lens[i] = 0; kept[i] = 0; }
-}
-__global__ __launch_bounds__(256) void k_kept_slots(const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off, unsigned n, unsigned* __restrict__ slots) {
-    unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && kept[i]) slots[path_off[i]] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,10 +156,41 @@ static int excl_scan(orip_ctx* c, const T* in, T* out, size_t n, DBuf& tmp) {
     return 0;
 }
 
-extern "C" int orip_find_contours(orip_ctx* c) {
+// State kept between orip_contours_prepare and the per-layer trace calls (device buffers live in lane 0's scratch).
+struct Prep04 {
+    bool ready = false;
+    unsigned M = 0, NC = 0;
+    std::vector<unsigned> h_cs, layer_first;       // comp_start on the host; first component of every layer (+ sentinel)
+    const unsigned* order = nullptr;                // components by (layer, size descending)
+    WalkArgs A;                                     // shared arguments (state bytes, keys, lin, comp_start, memo, winfo, total_fg)
+    unsigned F[ORIP_MAX_LAYERS];                    // log capacity factor of the trace in flight
+    bool launched[ORIP_MAX_LAYERS];
+};
+void orip_contours_free(orip_ctx* c) { delete static_cast<Prep04*>(c->prep04); c->prep04 = nullptr; }
+
+__global__ __launch_bounds__(256) void k_comp_order_keys(const unsigned* __restrict__ keys, const unsigned* __restrict__ cs, unsigned nc, unsigned long long* __restrict__ k, unsigned* __restrict__ idx) {
+    unsigned c = blockIdx.x * 256 + threadIdx.x;
+    if (c < nc) { k[c] = ((unsigned long long)(keys[cs[c]] >> 26) << 32) | (unsigned)~(cs[c + 1] - cs[c]); idx[c] = c; }
+}
+__global__ __launch_bounds__(256) void k_clear_visited_layer(u8* __restrict__ st, const unsigned* __restrict__ lin, int64_t m) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) st[lin[i]] &= (u8)~ST_VIS;
+}
+__global__ __launch_bounds__(256) void k_kept_slots_base(const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off, unsigned n, unsigned base, unsigned* __restrict__ slots) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && kept[i]) slots[path_off[i]] = base + i;
+}
+
+// Everything of stage 04 that is batched over the layers: thinning, components, state bytes, the raster-ordered pixel list
+// sorted by component, the per-layer schedule.  Runs on lane 0 and ends synchronised.
+extern "C" int orip_contours_prepare(orip_ctx* c) {
     if (!c->edges.p || c->K < 1) ORIP_FAIL(c, "no edges resident (run orip_detect_edges or orip_set_edges)");
     const int H = c->H, W = c->W, K = c->K;
     if (H > 8192 || W > 8192) ORIP_FAIL(c, "image %dx%d exceeds the 8192x8192 limit of the component key packing", W, H);
+    if (!c->prep04) c->prep04 = new Prep04();
+    Prep04& R = *static_cast<Prep04*>(c->prep04);
+    R.ready = false;
+    for (int l = 0; l < ORIP_MAX_LAYERS; l++) { R.launched[l] = false; R.F[l] = 0; }
     const size_t plane = (size_t)H * W; const int64_t n = (int64_t)plane * K;
     // ---- thinning_zhangsuen (04:35-99): <=120 iterations of two sub-iterations, until nothing is deleted
     HIPC(c, c->skel.ensure(plane * K + 16));
@@ -211,7 +225,6 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     HIPC(c, hipMemsetAsync(d_cnt + nblk, 0, sizeof(unsigned), LN(c).stream));
     { ProfScope ps(c, "k_compact_count"); hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), n, d_cnt); }
     ORIP_TRY(excl_scan<unsigned>(c, d_cnt, d_boff, (size_t)nblk + 1, LN(c).tmpF));
-    // per-layer fg totals = differences of the scan at layer boundaries (blocks do not align with layers -> count on host from scan + partial)
     unsigned M = 0;
     HIPC(c, hipMemcpyAsync(&M, d_boff + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
@@ -220,7 +233,8 @@ extern "C" int orip_find_contours(orip_ctx* c) {
         P.n = 0; P.total = 0;
         HIPC(c, P.off.ensure(8)); HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
     }
-    if (M == 0) return 0;
+    R.M = M; R.NC = 0;
+    if (M == 0) { HIPC(c, hipStreamSynchronize(LN(c).stream)); R.ready = true; return 0; }
     // keys / lin (double buffers for the sort)
     HIPC(c, LN(c).vtmp[0].ensure((size_t)M * 4 * 4 + 64));
     unsigned* keys_in = LN(c).vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
@@ -242,105 +256,156 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     HIPC(c, hipMemcpyAsync(&last2[1], head + (M - 1), 4, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     const unsigned NC = last2[0] + last2[1];
+    R.NC = NC;
     HIPC(c, LN(c).vtmp[2].ensure((size_t)(NC + 2) * 4 + 64));
     unsigned* comp_start = LN(c).vtmp[2].as<unsigned>();
     hipLaunchKernelGGL(k_comp_starts, dim3(cdiv(M, 256)), block, 0, LN(c).stream, head, head_scan, (int64_t)M, comp_start, NC);
-    // per-layer fg totals and first-component index: binary search on the sorted keys (host side, small readback)
-    std::vector<unsigned> h_cs(NC + 1), h_keyfirst(NC);
-    HIPC(c, hipMemcpyAsync(h_cs.data(), comp_start, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, LN(c).stream));
-    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    R.h_cs.assign(NC + 1, 0); std::vector<unsigned> h_keyfirst(NC);
+    HIPC(c, hipMemcpyAsync(R.h_cs.data(), comp_start, (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, LN(c).stream));
     // layer of each component (key of its first element)
     HIPC(c, LN(c).vtmp[3].ensure((size_t)NC * 4 + 64));
-    WalkArgs A; memset(&A, 0, sizeof(A));
+    WalkArgs& A = R.A; memset(&A, 0, sizeof(A));
     A.H = H; A.W = W; A.plane = (int64_t)plane; A.st = c->tmpC.as<u8>(); A.keys = keys; A.lin = lin; A.comp_start = comp_start; A.nc = NC;
     hipLaunchKernelGGL(k_gather_head_layers, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, keys, comp_start, NC, LN(c).vtmp[3].as<unsigned>());
     HIPC(c, hipMemcpyAsync(h_keyfirst.data(), LN(c).vtmp[3].p, (size_t)NC * 4, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
-    std::vector<unsigned> layer_first(K + 1, NC);
+    std::vector<unsigned>& layer_first = R.layer_first; layer_first.assign(K + 1, NC);
     for (unsigned i = NC; i-- > 0;) layer_first[h_keyfirst[i]] = i;
     for (int l = K - 1; l >= 0; l--) if (layer_first[l] == NC && l + 1 <= K) layer_first[l] = layer_first[l + 1];
     layer_first[K] = NC;
-    for (int l = 0; l < K; l++) A.total_fg[l] = (long long)h_cs[layer_first[l + 1]] - (long long)h_cs[layer_first[l]];
-    // the largest-first schedule
+    for (int l = 0; l < K; l++) A.total_fg[l] = (long long)R.h_cs[layer_first[l + 1]] - (long long)R.h_cs[layer_first[l]];
+    // per-layer largest-first schedule: components sorted by (layer, size descending); layer l owns order[layer_first[l] .. layer_first[l+1])
     {
-        HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 16 + 64));
-        unsigned* szin = LN(c).vtmp[5].as<unsigned>(); unsigned* szout = szin + NC; unsigned* idin = szout + NC; unsigned* idout = idin + NC;
-        hipLaunchKernelGGL(k_comp_sizes, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, comp_start, NC, szin, idin);
+        HIPC(c, LN(c).vtmp[5].ensure((size_t)NC * 24 + 64));
+        unsigned long long* kin = LN(c).vtmp[5].as<unsigned long long>(); unsigned long long* kout = kin + NC; unsigned* idin = (unsigned*)(kout + NC); unsigned* idout = idin + NC;
+        hipLaunchKernelGGL(k_comp_order_keys, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, keys, comp_start, NC, kin, idin);
         size_t bytes = 0;
-        HIPC(c, rocprim::radix_sort_pairs_desc(nullptr, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, LN(c).stream));
+        HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, idin, idout, (size_t)NC, 0, 40, LN(c).stream));
         HIPC(c, LN(c).tmpF.ensure(bytes + 16));
-        HIPC(c, rocprim::radix_sort_pairs_desc(LN(c).tmpF.p, bytes, szin, szout, idin, idout, (size_t)NC, 0, 32, LN(c).stream));
+        HIPC(c, rocprim::radix_sort_pairs(LN(c).tmpF.p, bytes, kin, kout, idin, idout, (size_t)NC, 0, 40, LN(c).stream));
         HIPC(c, LN(c).vtmp[3].ensure((size_t)NC * 4 + 64));
         HIPC(c, hipMemcpyAsync(LN(c).vtmp[3].p, idout, (size_t)NC * 4, hipMemcpyDeviceToDevice, LN(c).stream));
-        A.comp_order = LN(c).vtmp[3].as<unsigned>();
+        R.order = LN(c).vtmp[3].as<unsigned>();
     }
-    // ---- trace pass (walker.h): one wave per component records step codes, bounce trajectories and one WalkInfo per walk
-    const bool walk_dbg = getenv("ORIP_WALK_DBG") != nullptr;
-    const unsigned nslots = 2u * M;
-    const size_t memo_bytes = plane * (size_t)K * 8 * 4;                      // memo plane: one word per (pixel, incoming direction)
-    HIPC(c, LN(c).vtmp[6].ensure(memo_bytes + 64));
-    HIPC(c, LN(c).vtmp[8].ensure((size_t)nslots * sizeof(WalkInfo) + 64));    // walk records
+    // shared trace state: memo plane (one word per pixel and incoming direction) and walk records (two slots per skeleton pixel)
+    HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
+    HIPC(c, LN(c).vtmp[8].ensure((size_t)2 * M * sizeof(WalkInfo) + 64));
+    A.memo = LN(c).vtmp[6].as<unsigned>(); A.winfo = LN(c).vtmp[8].as<WalkInfo>();
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    R.ready = true;
+    return 0;
+}
+
+// Enqueues the trace pass of one layer on the calling lane's stream (walker.h: one wave per component records step codes, bounce
+// trajectories and one WalkInfo per walk).  The logs of the layer live in the lane's scratch; the kernel addresses them with the
+// global formula (cap_factor * comp_start + ...), so the base pointers are shifted by the layer's first component.
+static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F) {
+    const unsigned c0 = R.layer_first[layer], c1 = R.layer_first[layer + 1];
+    const unsigned b0 = R.h_cs[c0], b1 = R.h_cs[c1];
+    const unsigned Ml = b1 - b0, NCl = c1 - c0;
+    const size_t plane = (size_t)R.A.plane;
+    if ((uint64_t)F * R.M + (uint64_t)256 * R.NC + 64 >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the walk logs (factor %u)", F);
+    const size_t nlog = (size_t)F * Ml + (size_t)64 * NCl + 8, nstep = (size_t)F * Ml + (size_t)256 * NCl + 8;
+    HIPC(c, LN(c).vtmp[7].ensure(nlog * 16 + 64));
+    HIPC(c, LN(c).vtmp[9].ensure(nstep + 64));
+    WalkArgs A = R.A;
+    A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)F * b0 + (size_t)64 * c0);
+    A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)F * b0 + (size_t)256 * c0);
+    A.cap_factor = F; A.comp_order = R.order + c0; A.nc = NCl;
+    int* d_over = LN(c).flags.as<int>() + 20; A.overflow = d_over;
+    HIPC(c, hipMemsetAsync(A.memo + plane * 8 * layer, 0, plane * 8 * 4, LN(c).stream));
+    HIPC(c, hipMemsetAsync(A.winfo + 2 * (size_t)b0, 0, (size_t)2 * Ml * sizeof(WalkInfo), LN(c).stream));
+    HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
+    if (getenv("ORIP_WALK_DBG")) {          // per-component counters (walks, steps, memo hits, closed cycles, tile loads, size)
+        HIPC(c, LN(c).vtmp[10].ensure((size_t)NCl * 64 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[10].p, 0, (size_t)NCl * 64, LN(c).stream));
+        A.dbg = LN(c).vtmp[10].as<unsigned long long>() - 8ull * c0;
+    }
+    { ProfScope ps(c, "k_trace"); hipLaunchKernelGGL(k_trace, dim3(NCl), dim3(64), 0, LN(c).stream, A); }
+    HIPC(c, hipGetLastError());
+    R.F[layer] = F; R.launched[layer] = true;
+    return 0;
+}
+// Waits for the trace of the layer (retrying with larger logs on overflow), then sizes, allocates and writes its contours.
+static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
+    const unsigned c0 = R.layer_first[layer], c1 = R.layer_first[layer + 1];
+    const unsigned b0 = R.h_cs[c0], b1 = R.h_cs[c1];
+    const unsigned Ml = b1 - b0;
+    const size_t plane = (size_t)R.A.plane;
+    dim3 block(256);
     int* d_over = LN(c).flags.as<int>() + 20;
-    A.memo = LN(c).vtmp[6].as<unsigned>(); A.winfo = LN(c).vtmp[8].as<WalkInfo>(); A.overflow = d_over;
-    for (unsigned F = 64;; F *= 4) {
-        if ((uint64_t)F * M + (uint64_t)256 * NC + 64 >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the walk logs (factor %u)", F);
-        const size_t nlog = (size_t)F * M + (size_t)64 * NC + 8, nstep = (size_t)F * M + (size_t)256 * NC + 8;
-        HIPC(c, LN(c).vtmp[7].ensure(nlog * 16 + 64));
-        HIPC(c, LN(c).vtmp[9].ensure(nstep + 64));
-        A.logbuf = LN(c).vtmp[7].as<unsigned>(); A.steplog = LN(c).vtmp[9].as<u8>(); A.cap_factor = F;
-        HIPC(c, hipMemsetAsync(A.memo, 0, memo_bytes, LN(c).stream));
-        HIPC(c, hipMemsetAsync(A.winfo, 0, (size_t)nslots * sizeof(WalkInfo), LN(c).stream));
-        HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
-        if (walk_dbg) { HIPC(c, LN(c).vtmp[10].ensure((size_t)NC * 8 * 8 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[10].p, 0, (size_t)NC * 64, LN(c).stream)); A.dbg = LN(c).vtmp[10].as<unsigned long long>(); }
-        { ProfScope ps(c, "k_trace"); hipLaunchKernelGGL(k_trace, dim3(NC), dim3(64), 0, LN(c).stream, A); }
-        HIPC(c, hipGetLastError());
+    for (;;) {
         int over = 0;
         HIPC(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, LN(c).stream));
         HIPC(c, hipStreamSynchronize(LN(c).stream));
         if (!over) break;
-        hipLaunchKernelGGL(k_clear_visited, dim3(cdiv(M, 256)), block, 0, LN(c).stream, c->tmpC.as<u8>(), keys, lin, (int64_t)M, (int64_t)plane);   // retry with larger logs
+        hipLaunchKernelGGL(k_clear_visited_layer, dim3(cdiv(Ml, 256)), block, 0, LN(c).stream, R.A.st + plane * layer, R.A.lin + b0, (int64_t)Ml);   // retry with larger logs
+        ORIP_TRY(trace_launch(c, R, layer, R.F[layer] * 4));
     }
-    if (walk_dbg) {
-        std::vector<unsigned long long> h((size_t)NC * 8); std::vector<unsigned> ho(NC);
-        hipMemcpy(h.data(), A.dbg, h.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(ho.data(), A.comp_order, (size_t)NC * 4, hipMemcpyDeviceToHost);
-        unsigned long long tot[8] = {0}; for (size_t i = 0; i < h.size(); i++) tot[i % 8] += h[i];
-        fprintf(stderr, "[walk dbg] NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n", NC, M, A.cap_factor, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6]);
-        for (int r = 0; r < 4 && r < (int)NC; r++) { const unsigned long long* d = &h[(size_t)ho[r] * 8]; fprintf(stderr, "   comp#%d fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n", r, d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]); }
+    if (getenv("ORIP_WALK_DBG")) {
+        const unsigned NCl = c1 - c0;
+        std::vector<unsigned long long> h((size_t)NCl * 8);
+        hipMemcpy(h.data(), LN(c).vtmp[10].p, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long tot[8] = {0}; size_t big = 0;
+        for (size_t i = 0; i < h.size(); i++) tot[i % 8] += h[i];
+        for (size_t i = 0; i < NCl; i++) if (h[i * 8 + 7] > h[big * 8 + 7]) big = i;
+        const unsigned long long* d = &h[big * 8];
+        fprintf(stderr, "[walk dbg] layer %d NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu | largest fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n",
+                layer, NCl, Ml, R.F[layer], tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
     }
-    // ---- offsets: exclusive scans over the walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
+    // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
+    const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
     HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
     unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1);
     unsigned* kept = (unsigned*)(pts_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
-    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A.winfo, nslots, lens, kept);
+    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, R.A.winfo + sl0, nslots, lens, kept);
     ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, (size_t)nslots + 1, LN(c).tmpF));
     ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, (size_t)nslots + 1, LN(c).tmpF));
-    std::vector<unsigned long long> h_pb(K + 1); std::vector<unsigned> h_qb(K + 1);
-    for (int l = 0; l <= K; l++) {
-        const size_t sl = 2 * (size_t)h_cs[layer_first[l]];
-        HIPC(c, hipMemcpyAsync(&h_pb[l], pts_off + sl, 8, hipMemcpyDeviceToHost, LN(c).stream));
-        HIPC(c, hipMemcpyAsync(&h_qb[l], path_off + sl, 4, hipMemcpyDeviceToHost, LN(c).stream));
-    }
+    unsigned long long h_pts = 0; unsigned h_paths = 0;
+    HIPC(c, hipMemcpyAsync(&h_pts, pts_off + nslots, 8, hipMemcpyDeviceToHost, LN(c).stream));
+    HIPC(c, hipMemcpyAsync(&h_paths, path_off + nslots, 4, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
-    A.pts_off = pts_off; A.path_off = path_off;
-    for (int l = 0; l < K; l++) {
-        DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
-        A.layer_pts_base[l] = h_pb[l]; A.layer_path_base[l] = h_qb[l];
-        P.total = (int64_t)(h_pb[l + 1] - h_pb[l]);
-        P.n = (int64_t)(h_qb[l + 1] - h_qb[l]);
-        HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
-        HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
-        HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
-        A.pts[l] = P.pts.as<int32_t>(); A.off[l] = P.off.as<int64_t>();
-    }
-    // ---- write pass: one wave per kept walk (prefix sums of direction codes + indexed copies of recorded tails)
-    const unsigned n_kept = h_qb[K];
-    if (n_kept) {
-        hipLaunchKernelGGL(k_kept_slots, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, nslots, kept_slots);
+    DPolys& P = c->polys[ORIP_SLOT_CONTOURS][layer];
+    P.total = (int64_t)h_pts; P.n = (int64_t)h_paths;
+    HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
+    HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
+    HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
+    if (h_paths) {
+        WalkArgs A = R.A;
+        A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)R.F[layer] * b0 + (size_t)64 * c0);
+        A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
+        A.cap_factor = R.F[layer];
+        A.pts_off = pts_off - sl0; A.path_off = path_off - sl0;          // indexed by global slot
+        A.layer_pts_base[layer] = 0; A.layer_path_base[layer] = 0;
+        A.pts[layer] = P.pts.as<int32_t>(); A.off[layer] = P.off.as<int64_t>();
+        hipLaunchKernelGGL(k_kept_slots_base, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, nslots, sl0, kept_slots);
         ProfScope ps(c, "k_write_walks");
-        hipLaunchKernelGGL(k_write_walks, dim3(std::min(n_kept, 262144u)), dim3(64), 0, LN(c).stream, A, kept_slots, n_kept);
+        hipLaunchKernelGGL(k_write_walks, dim3(std::min(h_paths, 262144u)), dim3(64), 0, LN(c).stream, A, kept_slots, h_paths);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(LN(c).stream));   // the per-layer stages that follow run on other streams
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    R.launched[layer] = false;
+    return 0;
+}
+
+// Contours of one layer (after orip_contours_prepare).  Runs on the layer's own lane, so different layers can be traced from
+// different host threads at the same time and a finished layer can move on to stages 05-08 while others are still walking.
+extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
+    Prep04* R = static_cast<Prep04*>(c->prep04);
+    if (!R || !R->ready) ORIP_FAIL(c, "orip_contours_prepare has not run");
+    if (layer < 0 || layer >= c->K) ORIP_FAIL(c, "bad layer %d", layer);
+    if (R->M == 0 || R->layer_first[layer] == R->layer_first[layer + 1]) return 0;
+    LaneGuard lane(layer + 1);
+    ORIP_TRY(trace_launch(c, *R, layer, 64));
+    return trace_finish(c, *R, layer);
+}
+
+extern "C" int orip_find_contours(orip_ctx* c) {
+    ORIP_TRY(orip_contours_prepare(c));
+    Prep04& R = *static_cast<Prep04*>(c->prep04);
+    if (R.M == 0) return 0;
+    // every layer's trace is enqueued on its own stream first, so the long serial walks of all layers overlap
+    for (int l = 0; l < c->K; l++) if (R.layer_first[l] != R.layer_first[l + 1]) { LaneGuard lane(l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
+    for (int l = 0; l < c->K; l++) if (R.launched[l]) { LaneGuard lane(l + 1); ORIP_TRY(trace_finish(c, R, l)); }
     return 0;
 }
 

@@ -76,25 +76,41 @@ __global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict
 // pairwise perimeter keeps numpy's exact tree: every leaf of the tree has 64..128 elements (n2 = n/2 - (n/2)%8 >= 64 for
 // n > 128), so each multiple of 64 lies in exactly one leaf; the thread that holds the first multiple of 64 of a leaf sums
 // that leaf in numpy's 8-accumulator order, and thread 0 then combines the leaf sums with the explicit-stack traversal.
-template <int KIND>
-__device__ float pairwise_long_combine(const float* __restrict__ leafsum, int64_t n) {
-    int64_t fs[48], fn[48]; int fstate[48]; float fleft[48];
-    int sp = 1; fs[0] = 0; fn[0] = n; fstate[0] = 0;
+// Evaluates numpy's pairwise tree below the node (s0, n0) from the leaf sums; `part`/`depth_left` let the root traversal stop at
+// nodes that other threads have already reduced (code = path bits from the root).
+__device__ float pairwise_subtree(const float* __restrict__ leafsum, int64_t s0, int64_t n0, const float* part, int depth_left) {
+    int64_t fs[48], fn[48]; int fstate[48], fdep[48]; unsigned fcode[48]; float fleft[48];
+    int sp = 1; fs[0] = s0; fn[0] = n0; fstate[0] = 0; fdep[0] = depth_left; fcode[0] = 0;
     float ret = 0.f;
     while (sp > 0) {
         int t = sp - 1;
         if (fn[t] <= 128) { ret = leafsum[(fs[t] + 63) >> 6]; sp--; continue; }
+        if (part && fdep[t] == 0) { ret = part[fcode[t]]; sp--; continue; }
         int64_t n2 = fn[t] / 2; n2 -= n2 % 8;
-        if (fstate[t] == 0) { fstate[t] = 1; fs[sp] = fs[t]; fn[sp] = n2; fstate[sp] = 0; sp++; }
-        else if (fstate[t] == 1) { fleft[t] = ret; fstate[t] = 2; fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fstate[sp] = 0; sp++; }
+        if (fstate[t] == 0) { fstate[t] = 1; fs[sp] = fs[t]; fn[sp] = n2; fstate[sp] = 0; fdep[sp] = fdep[t] - 1; fcode[sp] = fcode[t] << 1; sp++; }
+        else if (fstate[t] == 1) { fleft[t] = ret; fstate[t] = 2; fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fstate[sp] = 0; fdep[sp] = fdep[t] - 1; fcode[sp] = (fcode[t] << 1) | 1u; sp++; }
         else { ret = fleft[t] + ret; sp--; }
     }
     return ret;
 }
+// one numpy leaf (8 <= n <= 128 elements from s) summed by 8 lanes: lane j owns accumulator r[j]; the xor tree reproduces
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (float addition commutes), the n % 8 tail is added in order
+template <int KIND>
+__device__ __forceinline__ float pairwise_leaf_g8(const int32_t* __restrict__ xy, int64_t s, int64_t n, int j) {
+    auto el = [&](int64_t i) { return KIND == 0 ? vs::seg_len_f32(xy, s + i) : vs::seg_hypot_f32(xy, s + i); };
+    const int64_t lim = n - (n % 8);
+    float r = el(j);
+    for (int64_t i = 8 + j; i < lim; i += 8) r += el(i);
+    r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+    for (int64_t i = lim; i < n; i++) r += el(i);
+    return r;
+}
+#define ORIP_PW_DEPTH 8
 __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
                                                              PolyFeat* __restrict__ out, float* __restrict__ leafbuf) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
+    __shared__ float part[1 << ORIP_PW_DEPTH];
     for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
         PolyFeat f = out[i];
         const int64_t n = f.n;                     // already the open view when requested
@@ -122,13 +138,28 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
         if (what & 3) {
             const int64_t ns = n - 1;               // number of segments
             float* ls = leafbuf + (off[i] >> 6) + 2 * i;
-            for (int64_t pm = (int64_t)tid * 64; pm < ns; pm += 256 * 64) {
+            const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group and turn
+            for (int64_t pm = (int64_t)grp * 64; pm < ns; pm += 32 * 64) {
                 int64_t s = 0, len = ns;
                 while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
-                if (((s + 63) >> 6) << 6 == pm) ls[pm >> 6] = (what & 1) ? vs::pairwise_leaf<0>(p, s, len) : vs::pairwise_leaf<1>(p, s, len);
+                if (((s + 63) >> 6) << 6 == pm) {   // every multiple of 64 lies in exactly one leaf; its first one owns the leaf
+                    float v = (what & 1) ? pairwise_leaf_g8<0>(p, s, len, j) : pairwise_leaf_g8<1>(p, s, len, j);
+                    if (j == 0) ls[pm >> 6] = v;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            {   // thread t reduces the subtree reached by the ORIP_PW_DEPTH path bits of t (idle when the path ends in a leaf earlier)
+                int64_t s = 0, len = ns; bool mine = true;
+                for (int lvl = ORIP_PW_DEPTH - 1; lvl >= 0; lvl--) {
+                    if (len <= 128) { mine = false; break; }
+                    int64_t n2 = len / 2; n2 -= n2 % 8;
+                    if ((tid >> lvl) & 1) { s += n2; len -= n2; } else len = n2;
+                }
+                if (mine) part[tid] = pairwise_subtree(ls, s, len, nullptr, 0);
             }
             __syncthreads();
-            if (tid == 0) per = (what & 1) ? pairwise_long_combine<0>(ls, ns) : pairwise_long_combine<1>(ls, ns);
+            if (tid == 0) per = pairwise_subtree(ls, 0, ns, part, ORIP_PW_DEPTH);
         }
         if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; }
         __syncthreads();
@@ -248,76 +279,72 @@ __global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict
         __syncthreads();
     }
 }
-// Grid-pruned variant (same selection rule, same tie-break, n <= 16000 and int16 coordinates): the entry points (start of every
-// polyline, end of every polyline that may be entered reversed) are bucketed into a G x G grid held in LDS next to the end points.
-// A greedy step scans the (2r+1)^2 cells around the cursor, r = 1, 3, 7, ...; it is final as soon as the best squared distance is
-// below the squared gap between the cursor and the nearest unscanned cell (every unscanned entry is at least that far, so it can
-// neither win nor tie), or the window covers the grid.  One barrier per scan; all threads track the cursor redundantly.
-__global__ __launch_bounds__(1024) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
-                                                          int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+// Grid-pruned variant (same selection rule, same tie-break, n <= 11000 or so and int16 coordinates): the entry points (start of
+// every polyline, end of every polyline that may be entered reversed) are bucketed into a G x G grid held in LDS next to the end
+// points.  A greedy step scans the (2r+1)^2 cells around the cursor, r = 1, 3, 7, ...; it is final as soon as the best squared
+// distance is below the squared gap between the cursor and the nearest unscanned cell (every unscanned entry is at least that far,
+// so it can neither win nor tie), or the window covers the grid.  The chain of steps is strictly serial and a step looks at a few
+// dozen entries, so ONE wavefront runs it: no barriers, no cross-wave exchange, and no other wave competing for the SIMD.
+__global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ flips, unsigned long long* __restrict__ dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     short4* P = reinterpret_cast<short4*>(smem);                                   // (sx, sy, ex, ey)
     unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // G*G + 1 cell starts
     uint16_t* Eid = reinterpret_cast<uint16_t*>(cst + (G * G + 1));                // entries sorted by cell: idx << 1 | end
     uint8_t* stt = reinterpret_cast<uint8_t*>(Eid + 2 * (size_t)n);                // bit0 used, bit1 closed (rule07)
-    __shared__ unsigned long long wbest[2][16];
-    __shared__ int red[4][16];
-    __shared__ unsigned wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     // ---- load + bounding box
     int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = lane; i < n; i += 64) {
         NNEnds e = ends[i];
         P[i] = make_short4((short)e.sx, (short)e.sy, (short)e.ex, (short)e.ey);
         stt[i] = (uint8_t)((i == seed ? 1 : 0) | ((rule07 && e.closed) ? 2 : 0));
         mnx = min(mnx, min(e.sx, e.ex)); mxx = max(mxx, max(e.sx, e.ex)); mny = min(mny, min(e.sy, e.ey)); mxy = max(mxy, max(e.sy, e.ey));
     }
     for (int o = 32; o > 0; o >>= 1) { mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); }
-    if (lane == 0) { red[0][wave] = mnx; red[1][wave] = mny; red[2][wave] = mxx; red[3][wave] = mxy; }
-    for (int i = tid; i <= G * G; i += 1024) cst[i] = 0;
+    for (int i = lane; i <= G * G; i += 64) cst[i] = 0;
     __syncthreads();
-    for (int w = 0; w < 16; w++) { mnx = min(mnx, red[0][w]); mny = min(mny, red[1][w]); mxx = max(mxx, red[2][w]); mxy = max(mxy, red[3][w]); }
     const int ox = mnx, oy = mny;
     const int cs = max(1, (max(mxx - mnx, mxy - mny) + G) / G);                     // (coord - origin) / cs < G for every end point
     // ---- counting sort of the entries by cell
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = lane; i < n; i += 64) {
         short4 e = P[i];
         atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u);
         if (!(stt[i] & 2)) atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u);
     }
     __syncthreads();
-    {   // exclusive scan of G*G counts: 4 consecutive cells per thread (G <= 64)
-        unsigned v[4], s = 0;
-        for (int j = 0; j < 4; j++) { int cidx = tid * 4 + j; v[j] = cidx < G * G ? cst[cidx] : 0u; s += v[j]; }
+    {   // exclusive scan of the G*G counts: a run of consecutive cells per lane
+        const int per = (G * G + 63) / 64, c0 = lane * per, c1 = min(G * G, c0 + per);
+        unsigned s = 0;
+        for (int cc = c0; cc < c1; cc++) s += cst[cc];
         unsigned inc = s;
         for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned base = 0; for (int w = 0; w < wave; w++) base += wsum[w];
-        unsigned run = base + inc - s;
-        for (int j = 0; j < 4; j++) { int cidx = tid * 4 + j; if (cidx < G * G) cst[cidx] = run; run += v[j]; }
-        if (tid == 1023) cst[G * G] = run;
+        unsigned run = inc - s;
+        for (int cc = c0; cc < c1; cc++) { unsigned v = cst[cc]; cst[cc] = run; run += v; }
+        if (lane == 63) cst[G * G] = inc;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {        // scatter; cst[c] ends up as the END of cell c, i.e. start(c) = c ? cst[c-1] : 0
+    for (int i = lane; i < n; i += 64) {         // scatter; cst[c] ends up as the END of cell c, i.e. start(c) = c ? cst[c-1] : 0
         short4 e = P[i];
         Eid[atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u)] = (uint16_t)(i << 1);
         if (!(stt[i] & 2)) Eid[atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u)] = (uint16_t)((i << 1) | 1);
     }
     int cx, cy;
     { short4 e = P[seed]; if (stt[seed] & 2) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; } }
-    if (tid == 0) { order[0] = seed; flips[0] = 0; }
+    if (lane == 0) { order[0] = seed; flips[0] = 0; }
     __syncthreads();
-    int prev = seed, par = 0;
+    int prev = seed;
+    unsigned long long d_rounds = 0, d_scanned = 0, d_full = 0;
     for (int step = 1; step < n; step++) {
         const int gx = (cx - ox) / cs, gy = (cy - oy) / cs;
         unsigned long long best = ~0ULL;
         for (int r = 1;; r = 2 * r + 1) {
             const int x0 = max(0, gx - r), x1 = min(G - 1, gx + r), y0 = max(0, gy - r), y1 = min(G - 1, gy + r);
             unsigned long long mine = ~0ULL;
-            for (int row = y0 + wave; row <= y1; row += 16) {
+            for (int row = y0; row <= y1; row++) {
                 const int c0 = row * G + x0, c1 = row * G + x1;
                 const unsigned lo = c0 ? cst[c0 - 1] : 0u, hi = cst[c1];
+                if (dbg) d_scanned += hi - lo;
                 for (unsigned q = lo + lane; q < hi; q += 64) {
                     const unsigned id = Eid[q]; const int i = (int)(id >> 1);
                     if ((stt[i] & 1) || i == prev) continue;
@@ -328,13 +355,9 @@ __global__ __launch_bounds__(1024) void k_greedy_nn_grid(const NNEnds* __restric
                 }
             }
             for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(mine, o, 64); if (t < mine) mine = t; }
-            if (lane == 0) wbest[par][wave] = mine;
-            __syncthreads();
-            unsigned long long b = wbest[par][lane & 15];
-            for (int o = 8; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(b, o, 64); if (t < b) b = t; }
-            par ^= 1;
-            best = b;
-            if (x0 == 0 && y0 == 0 && x1 == G - 1 && y1 == G - 1) break;             // everything scanned
+            best = mine;
+            if (dbg) d_rounds++;
+            if (x0 == 0 && y0 == 0 && x1 == G - 1 && y1 == G - 1) { if (dbg) d_full++; break; }     // everything scanned
             if (best != ~0ULL) {
                 long long gap = 0x7fffffff;                                          // distance to the nearest unscanned cell, over the open sides
                 if (x0 > 0) gap = min(gap, (long long)(cx - (ox + x0 * cs)) + 1);
@@ -350,10 +373,11 @@ __global__ __launch_bounds__(1024) void k_greedy_nn_grid(const NNEnds* __restric
         float ds = nn_d2(e.x, e.y, cx, cy), de = nn_d2(e.z, e.w, cx, cy);
         const bool cl = (f & 2) != 0;
         const bool flip = cl ? false : !(ds <= de);
-        if (tid == 0) { stt[bi] = f | 1; order[step] = bi; flips[step] = flip ? 1 : 0; }
+        if (lane == 0) { stt[bi] = f | 1; order[step] = bi; flips[step] = flip ? 1 : 0; }
         if (cl || flip) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; }
         prev = bi;
     }
+    if (dbg && lane == 0) { dbg[0] = d_rounds; dbg[1] = d_scanned; dbg[2] = d_full; dbg[3] = (unsigned long long)cs; }
 }
 // 1 if every coordinate fits int16 (the LDS variant is then exact)
 __global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
@@ -466,7 +490,9 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     }
     if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {
         ProfScope ps(c, "k_greedy_nn");
-        hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(1024), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips);
+        unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
+        hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips, dbg);
+        if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
     } else if (n <= 16000 && !hs[1]) {
         ProfScope ps(c, "k_greedy_nn");
         hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, order, flips);

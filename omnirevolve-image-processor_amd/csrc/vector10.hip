@@ -322,27 +322,43 @@ __global__ __launch_bounds__(1024) void k_taps_sequential(const int2* __restrict
     if (threadIdx.x == 0) *n_acc_out = nacc;
 }
 
-extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers, const orip_params10* prm) {
-    if (!prm || n_layers < 0 || n_layers > ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
+// Stage 10 keeps one cumulative "forbidden" raster while it walks the layers from dark to light (10:166-212).  begin clears it,
+// every orip_dedup_cross_layer call handles the next layer of that order; the calls use their own lane (stream + scratch), so the
+// early layers can be processed while later ones are still in stages 04-08 on their lanes.
+extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
+    if (!prm) ORIP_FAIL(c, "bad arguments");
     const orip_params10 P = *prm;
     const int W = P.W, H = P.H;
     if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
     if (P.max_jump < 4.0) ORIP_FAIL(c, "max_join_jump_px < 4 is not supported (cut output is assumed jump-free)");
-    const int Wp = W + 2 * ORIP_PAD, Hp = H + 2 * ORIP_PAD;
     const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
     const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));
     if (rad_lines > ORIP_PAD - 2 || rad_taps > 200) ORIP_FAIL(c, "brush radius %d/%d too large for the padded raster", rad_lines, rad_taps);
+    LaneGuard lane(ORIP_LANE_CROSS);
     HIPC(c, LN(c).canvas.ensure((size_t)W * H + 64));
+    HIPC(c, hipMemsetAsync(LN(c).canvas.p, 0, (size_t)W * H, LN(c).stream));
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    c->p10 = P; c->p10_ready = true;
+    return 0;
+}
+
+extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) {
+    if (!c->p10_ready) ORIP_FAIL(c, "orip_dedup_cross_begin has not run");
+    const orip_params10 P = c->p10;
+    const int W = P.W, H = P.H;
+    LaneGuard lane(ORIP_LANE_CROSS);
+    const int Wp = W + 2 * ORIP_PAD, Hp = H + 2 * ORIP_PAD;
+    const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
+    const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));
     u8* forb = LN(c).canvas.as<u8>();
-    HIPC(c, hipMemsetAsync(forb, 0, (size_t)W * H, LN(c).stream));
     const int occ_w = (Wp + 63) >> 6, occ_h = (Hp + 31) >> 5;
     HIPC(c, LN(c).vtmp[9].ensure((size_t)Wp * Hp * 2 + (size_t)occ_w * occ_h + 64));
     u8* seeds = LN(c).vtmp[9].as<u8>(); u8* hd = seeds + (size_t)Wp * Hp; u8* occ = hd + (size_t)Wp * Hp;
     const bool tdbg = getenv("ORIP_TIME10") != nullptr;
     auto now = [&]() { hipStreamSynchronize(LN(c).stream); return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    for (int li = 0; li < n_layers; li++) {
-        const int layer = order[li];
+    {
+
         auto t0 = tdbg ? now() : std::chrono::steady_clock::time_point();
         if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
         DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
@@ -428,3 +444,11 @@ extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers,
     }
     return 0;
 }
+
+extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers, const orip_params10* prm) {
+    if (!prm || n_layers < 0 || n_layers > ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
+    ORIP_TRY(orip_dedup_cross_begin(c, prm));
+    for (int li = 0; li < n_layers; li++) ORIP_TRY(orip_dedup_cross_layer(c, order[li]));
+    return 0;
+}
+

@@ -62,28 +62,65 @@ struct WalkArgs {
     unsigned long long* dbg;           // optional counters, 8 per component
 };
 
+#ifndef ORIP_WALK_BATCH
+#define ORIP_WALK_BATCH 64u     // pending no-fresh states looked up together (at most one per lane)
+#endif
 namespace walk_detail {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WT 64
+#define WTP (WT + 4)
+// One wavefront walks one component.  The walk itself is a strictly serial chain executed by a wave that has its SIMD to itself,
+// so its speed is the number of instructions per step: the cursor is kept as global coordinates + linear index + offset inside a
+// 64x64 LDS window of the state bytes, the eight neighbours are read by lanes 0..7 through a per-lane constant offset, and the
+// previous pixel is excluded by its lane number (NEIGH8 is point-symmetric: the way back from a step in direction k is 7 - k).
 struct Wave {
     int lane;
-    u8 (*tile)[WT + 4];
+    u8* tile;                   // [WT][WTP]
     int tx0, ty0; bool have; unsigned nload;
-    __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0) {
-        __shared__ u8 lds_tile[WT][WT + 4];
-        tile = lds_tile;
+    int px, py; unsigned pl;    // cursor
+    int li;                     // cursor offset inside the window (set by probe)
+    int noff;                   // this lane's neighbour offset inside the window (lanes 0..7)
+    u8 myv;                     // state byte of this lane's neighbour (after probe)
+    u8* st; int W, H;
+    // Global stores inside the step loop would make every later s_waitcnt vmcnt(0) of the loop wait for a full store round trip, so
+    // the loop only writes LDS: visited marks go to the window at once and to `mlist` (flushed to memory, all lanes, before anything
+    // reads the state bytes from memory again); direction codes go to `sbuf` and reach the step log 64 at a time.
+    unsigned* mlist; int nm;    // pending marks: (linear index << 4) | state byte
+    u8* sbuf; unsigned codes_done;
+    __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0), px(0), py(0), pl(0), li(0), myv(0), st(nullptr), W(0), H(0) {
+        __shared__ u8 lds_tile[WT * WTP];
+        __shared__ unsigned lds_marks[64];
+        __shared__ u8 lds_codes[64];
+        tile = lds_tile; mlist = lds_marks; nm = 0; sbuf = lds_codes; codes_done = 0;
+        const int k = lane & 7;
+        noff = ((int)((0xA940u >> (2 * k)) & 3u) - 1) * WTP + (int)((0x9224u >> (2 * k)) & 3u) - 1;
     }
+    __device__ void init(u8* st_, int W_, int H_) { st = st_; W = W_; H = H_; }
     __device__ bool leader() const { return lane == 0; }
     __device__ unsigned l0() const { return (unsigned)lane; }
     __device__ unsigned nl() const { return 64u; }
     __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
-    // lane 0 loads, everybody gets the value: lane 0 is also the only lane that stores these words, and a lane always sees its own earlier stores
+    // lane 0 loads, everybody gets the value
     __device__ unsigned ld0(const unsigned* p) const { unsigned v = 0; if (lane == 0) v = *p; return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ void load_tile(const u8* st, int W, int H, int cx, int cy) {
+    __device__ void flush_marks() {
+        if (nm) { if (lane < nm) { const unsigned e = mlist[lane]; st[e >> 4] = (u8)(e & 15u); } nm = 0; }
+    }
+    // marks of the walk so far are in memory (before the state bytes are read from memory: next scan, next window)
+    __device__ void sync_marks() { flush_marks(); fence(); }
+    __device__ void begin_codes() { codes_done = 0; }
+    __device__ void put_code(u8* slog, unsigned room, unsigned idx, int k) {
+        if (lane == 0) sbuf[idx & 63u] = (u8)k;
+        if ((idx & 63u) == 63u) { const unsigned p = (idx & ~63u) + (unsigned)lane; if (p < room) slog[p] = sbuf[lane]; codes_done = idx + 1u; }
+    }
+    __device__ void finish_codes(u8* slog, unsigned room, unsigned steps) {
+        if (steps > codes_done) { const unsigned p = codes_done + (unsigned)lane; if (p < steps && p < room) slog[p] = sbuf[p & 63u]; }
+    }
+    __device__ void load_tile(int cx, int cy) {
+        flush_marks();
         fence();                                                      // earlier marks have reached memory
         tx0 = ((cx - WT / 2) >> 2) << 2; ty0 = cy - WT / 2;          // 4-byte aligned columns
         const int y = ty0 + lane;
-        u8* row = tile[lane];
+        u8* row = tile + lane * WTP;
         if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0u; }
         else if ((W & 3) == 0 && tx0 >= 0 && tx0 + WT <= W) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (size_t)y * W + tx0);
@@ -95,29 +132,42 @@ struct Wave {
         have = true; nload++;
         fence();
     }
-    // probe the 8 neighbours of (px,py); returns masks over NEIGH8 indices
-    __device__ void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
-        if (!have || px - tx0 < 1 || px - tx0 > WT - 2 || py - ty0 < 1 || py - ty0 > WT - 2) load_tile(st, W, H, px, py);
-        u8 v = 0; bool any = false;
-        if (lane < 8) {
-            int xx = px + (int)((0x9224u >> (2 * lane)) & 3u) - 1, yy = py + (int)((0xA940u >> (2 * lane)) & 3u) - 1;
-            v = tile[yy - ty0][xx - tx0];                         // out-of-image cells of the window hold 0
-            any = (v & ST_FG) && !(xx == pvx && yy == pvy);
-        }
-        myv = v;
-        m_any = (unsigned)(__ballot(any) & 0xffu);
-        m_unvis = (unsigned)(__ballot(any && !(v & ST_VIS)) & 0xffu);
-    }
-    __device__ u8 value_of(u8 myv, int k) const { return (u8)__shfl((int)myv, k, 64); }
-    // lane 0 marks pixel (x,y) visited: global memory and, when inside, the window
-    __device__ void mark(u8* st, int W, int x, int y, u8 v) {
+    __device__ void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; }
+    // marks the cursor pixel itself (start of a walk): global memory and, when inside, the window
+    __device__ void mark_cursor(u8 v) {
         if (lane == 0) {
-            st[(size_t)y * W + x] = (u8)(v | ST_VIS);
-            if (have && x >= tx0 && x < tx0 + WT && y >= ty0 && y < ty0 + WT) tile[y - ty0][x - tx0] = (u8)(v | ST_VIS);
+            st[pl] = (u8)(v | ST_VIS);
+            const int lx = px - tx0, ly = py - ty0;
+            if (have && (unsigned)lx < (unsigned)WT && (unsigned)ly < (unsigned)WT) tile[ly * WTP + lx] = (u8)(v | ST_VIS);
         }
     }
+    // neighbours of the cursor; kopp = NEIGH8 index of the previous pixel (8: none).  Masks over NEIGH8 indices.
+    __device__ void probe(int kopp, unsigned& m_any, unsigned& m_unvis) {
+        int lx = px - tx0, ly = py - ty0;
+        if (!have || (unsigned)(lx - 1) > (unsigned)(WT - 3) || (unsigned)(ly - 1) > (unsigned)(WT - 3)) { load_tile(px, py); lx = px - tx0; ly = py - ty0; }
+        li = ly * WTP + lx;
+        u8 v = 0;
+        if (lane < 8) v = tile[li + noff];                            // out-of-image cells of the window hold 0
+        const bool any = (v & ST_FG) && lane != kopp;
+        myv = v;
+        m_any = (unsigned)__ballot(any) & 0xffu;
+        m_unvis = (unsigned)__ballot(any && !(v & ST_VIS)) & 0xffu;
+    }
+    __device__ u8 value_of(int k) const { return (u8)__builtin_amdgcn_readlane((int)myv, k); }
+    // moves the cursor to neighbour k (after probe); mark: the neighbour becomes visited (it lies inside the window: the cursor is interior)
+    __device__ void step(int k, bool mark) {
+        const int dx = (int)((0x9224u >> (2 * k)) & 3u) - 1, dy = (int)((0xA940u >> (2 * k)) & 3u) - 1;
+        px += dx; py += dy; pl = (unsigned)((int)pl + dy * W + dx);
+        if (mark) {
+            const u8 v = (u8)(value_of(k) | ST_VIS);
+            if (lane == 0) { tile[li + dy * WTP + dx] = v; mlist[nm] = (pl << 4) | v; }
+            if (++nm == 64) flush_marks();
+        }
+    }
+    __device__ unsigned bcast(unsigned v, int src) const { return (unsigned)__shfl((int)v, src, 64); }
+    __device__ int first(bool pred) const { unsigned long long m = __ballot(pred); return m ? __ffsll((long long)m) - 1 : -1; }
     // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
-    __device__ unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
+    __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q += 64) {
             unsigned qq = q + lane; bool ok = false;
             if (qq < e) { u8 v = st[lin[qq]]; ok = ((v & need) == need) && !(v & ST_VIS); }
@@ -135,31 +185,46 @@ struct Wave {
 #else
 struct Wave {
     u8 nv[8]; unsigned nload = 0;
+    int px = 0, py = 0; unsigned pl = 0;
+    u8* st = nullptr; int W = 0, H = 0;
+    void init(u8* st_, int W_, int H_) { st = st_; W = W_; H = H_; }
     bool leader() const { return true; }
     unsigned l0() const { return 0u; }
     unsigned nl() const { return 1u; }
     void fence() const {}
     unsigned ld0(const unsigned* p) const { return *p; }
-    void probe(const u8* st, int W, int H, int px, int py, int pvx, int pvy, unsigned& m_any, unsigned& m_unvis, u8& myv) {
+    void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; }
+    void mark_cursor(u8 v) { st[pl] = (u8)(v | ST_VIS); }
+    void sync_marks() {}
+    void begin_codes() {}
+    void put_code(u8* slog, unsigned, unsigned idx, int k) { slog[idx] = (u8)k; }
+    void finish_codes(u8*, unsigned, unsigned) {}
+    void probe(int kopp, unsigned& m_any, unsigned& m_unvis) {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-        m_any = m_unvis = 0; myv = 0;
+        m_any = m_unvis = 0;
         for (int k = 0; k < 8; k++) {
             int xx = px + dxs[k], yy = py + dys[k]; nv[k] = 0;
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
             u8 v = st[(size_t)yy * W + xx]; nv[k] = v;
-            if ((v & ST_FG) && !(xx == pvx && yy == pvy)) { m_any |= 1u << k; if (!(v & ST_VIS)) m_unvis |= 1u << k; }
+            if ((v & ST_FG) && k != kopp) { m_any |= 1u << k; if (!(v & ST_VIS)) m_unvis |= 1u << k; }
         }
     }
-    u8 value_of(u8, int k) const { return nv[k]; }
-    void mark(u8* st, int W, int x, int y, u8 v) { st[(size_t)y * W + x] = (u8)(v | ST_VIS); }
-    unsigned scan(const unsigned* lin, const u8* st, unsigned q0, unsigned e, u8 need) const {
+    u8 value_of(int k) const { return nv[k]; }
+    void step(int k, bool mark) {
+        const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        px += dxs[k]; py += dys[k]; pl = (unsigned)py * (unsigned)W + (unsigned)px;
+        if (mark) st[pl] = (u8)(nv[k] | ST_VIS);
+    }
+    unsigned bcast(unsigned v, int) const { return v; }
+    int first(bool pred) const { return pred ? 0 : -1; }
+    unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) return q; }
         return e;
     }
     void scan2(int dx, int dy, int& ox, int& oy, int& tx, int& ty) const { ox = dx; oy = dy; tx = dx; ty = dy; }
 };
 #endif
-ORIP_HD inline int ffs8(unsigned m) { int k = 0; while (!((m >> k) & 1u)) k++; return k; }
+ORIP_HD inline int ffs8(unsigned m) { return __builtin_ctz(m); }
 // NEIGH8 (dx,dy) of 04:12 as packed 2-bit fields (value + 1)
 ORIP_HD inline int nbx(int k) { return (int)((0x9224u >> (2 * k)) & 3u) - 1; }
 ORIP_HD inline int nby(int k) { return (int)((0xA940u >> (2 * k)) & 3u) - 1; }
@@ -184,40 +249,44 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     u8* st = A.st + A.plane * layer;
     unsigned* memo = A.memo + (size_t)A.plane * layer * 8;
     const int W = A.W, H = A.H;
-    const long long fg_comp = (long long)fg, total_fg = A.total_fg[layer];
+    wv.init(st, W, H);
+    const long long total_fg = A.total_fg[layer];
     const unsigned F = A.cap_factor;
     const unsigned log_base = F * b + 64u * c, log_cap = F * fg + 64u;
     const unsigned step_base = F * b + 256u * c, step_cap = F * fg + 256u;
     unsigned logcur = 0, stepcur = 0;
     bool over = false;
     unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
-    auto put_step = [&](int k) { if (stepcur < step_cap) { if (wv.leader()) A.steplog[(size_t)step_base + stepcur] = (u8)k; } else over = true; stepcur++; };
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
         if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
     };
     // ---- phase 1: walks from endpoints (04:144-171); >= 2 points to be a path (04:168), >= 5 to survive vectorize_layer (04:224)
-    for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG | ST_END); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG | ST_END)) {
+    const unsigned long long g1 = (unsigned long long)(total_fg * 2);
+    for (unsigned q = wv.scan(A.lin, b, e, ST_FG | ST_END); q < e; q = wv.scan(A.lin, q + 1, e, ST_FG | ST_END)) {
         unsigned s = A.lin[q];
-        int px = (int)(s % W), py = (int)(s / W), pvx = -1, pvy = -1;
-        unsigned long long len = 1; const unsigned sbeg = step_base + stepcur;
-        wv.mark(st, W, px, py, ST_FG | ST_END);
-        long long guard = 0; d_w1++;
+        wv.set_cursor((int)(s % W), (int)(s / W));
+        const unsigned sbeg = step_base + stepcur;
+        u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
+        wv.mark_cursor(ST_FG | ST_END);
+        wv.begin_codes();
+        unsigned steps = 0; int kopp = 8; d_w1++;
         while (true) {
-            unsigned m_any, m_unvis; u8 myv;
-            wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
+            unsigned m_any, m_unvis;
+            wv.probe(kopp, m_any, m_unvis);
             if (!m_unvis) break;
-            int k = ffs8(m_unvis);
-            int nx = px + nbx(k), ny = py + nby(k);
-            u8 v = wv.value_of(myv, k);
-            put_step(k); len++; d_s1++;
-            wv.mark(st, W, nx, ny, v);
-            pvx = px; pvy = py; px = nx; py = ny;
+            const int k = ffs8(m_unvis);
+            const u8 v = wv.value_of(k);
+            if (steps < room) wv.put_code(slog, room, steps, k); else over = true;
+            steps++;
+            wv.step(k, true);
+            kopp = 7 - k;
             if (v & (ST_JUN | ST_END)) break;
-            guard++;
-            if (guard > total_fg * 2) break;
+            if ((unsigned long long)steps > g1) break;       // guard (04:163): counts the steps that went on
         }
-        wv.fence();       // marks of this walk are complete before the next scan
-        finish(2u * b + (q - b), len, (unsigned)(len - 1), sbeg, 0u, 0u, 0u);
+        stepcur += steps; d_s1 += steps;
+        wv.finish_codes(slog, room, steps);
+        wv.sync_marks();  // marks of this walk are complete before the next scan
+        finish(2u * b + (q - b), 1ull + steps, steps, sbeg, 0u, 0u, 0u);
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
     auto log_pos = [&](unsigned i, unsigned long long R, int& ox, int& oy) {   // position R steps after logged state i
@@ -225,71 +294,101 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         unsigned l = wv.ld0(&A.logbuf[4ull * f]) >> 3;
         ox = (int)(l % (unsigned)W); oy = (int)(l / (unsigned)W);
     };
-    for (unsigned q = wv.scan(A.lin, st, b, e, ST_FG); q < e; q = wv.scan(A.lin, st, q + 1, e, ST_FG)) {
+    // A walk that finds no fresh neighbour is on a trajectory that only depends on its state (pixel, incoming direction), so its
+    // states are looked up in / added to the memo.  The memo lives in HBM and a look-up per step would put one full memory latency
+    // on every step of a strictly serial chain; instead the walk runs ahead on the LDS window and parks its no-fresh states in the
+    // lanes (lane j = j-th pending state).  flush() then does what the reference order requires for all of them at once: the first
+    // pending state that is already known (to an older record, to this run, or to an earlier pending state) ends the walk there and
+    // the steps taken after it are dropped; otherwise all of them become provisional entries of this run.
+    const unsigned g2 = fg * 4u;                                  // guard of a leftover walk (04:199)
+    const unsigned nbatch = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
+    for (unsigned q = wv.scan(A.lin, b, e, ST_FG); q < e && !over; q = wv.scan(A.lin, q + 1, e, ST_FG)) {
         unsigned s = A.lin[q];
         const int x0 = (int)(s % W), y0 = (int)(s / W);
-        int px = x0, py = y0, pvx = -1, pvy = -1;
-        unsigned long long len = 1; const unsigned sbeg = step_base + stepcur;
-        { u8 sv = st[s]; wv.mark(st, W, px, py, sv); }
-        long long guard = 0; d_w2++;
-        unsigned n_own = 0, tail_i1 = 0, tail_R = 0;
+        wv.set_cursor(x0, y0);
+        const unsigned sbeg = step_base + stepcur;
+        u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
+        { u8 sv = st[s]; wv.mark_cursor(sv); }
+        wv.begin_codes();
+        d_w2++;
+        unsigned steps = 0;                   // steps taken = own points - 1 = value of the reference's guard counter at its check
+        unsigned long long tail_len = 0; unsigned tail_i1 = 0, tail_R = 0;
         unsigned nofresh = 0;                 // no-fresh states logged since the last fresh pixel: entries [run_begin, run_begin + nofresh)
-        while (true) {
-            unsigned m_any, m_unvis; u8 myv;
-            wv.probe(st, W, H, px, py, pvx, pvy, m_any, m_unvis, myv);
-            bool fresh = m_unvis != 0;
-            unsigned m = fresh ? m_unvis : m_any;
-            if (!m) break;
-            int k = ffs8(m);
-            int nx = px + nbx(k), ny = py + nby(k);
-            put_step(k); len++; n_own++; d_s2++;
-            if (fresh) wv.mark(st, W, nx, ny, wv.value_of(myv, k));
-            pvx = px; pvy = py; px = nx; py = ny;
-            if (px == x0 && py == y0) break;
-            guard++;
-            if (guard > fg_comp * 4) break;
-            if (fresh) { nofresh = 0; continue; }
+        unsigned nb = 0, myS = 0, steps_b = 0;                     // pending states; steps before the first of them
+        // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow
+        auto flush = [&]() -> int {
+            if (!nb) return 0;
             const unsigned run_begin = log_base + logcur;
-            const unsigned state = (((unsigned)py * (unsigned)W + (unsigned)px) << 3) | (unsigned)k;
-            const unsigned mi = wv.ld0(&memo[state]);
-            bool jumped = false;
-            if (mi) {
-                const unsigned i = mi - 1;
-                const unsigned ld = wv.ld0(&A.logbuf[4ull * i]), en = wv.ld0(&A.logbuf[4ull * i + 2]);
-                if (ld == state) {
-                    const unsigned long long R = (unsigned long long)(fg_comp * 4 + 1 - guard);     // points still to come until the guard fires
-                    if (en != 0) {                                    // committed trajectory of an earlier walk
-                        d_hit++;
-                        // this run's own no-fresh states become a transient record that runs into entry i, so later walks can jump from them too
-                        if (nofresh) { const unsigned end = run_begin + nofresh; if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; } logcur += nofresh; }
-                        tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
-                    } else if (i >= run_begin && i < run_begin + nofresh) {   // a state of this very run: the cycle [i, run_begin + nofresh) is closed
-                        d_det++;
-                        const unsigned end = run_begin + nofresh;
-                        if (wv.leader()) for (unsigned t = 0; t < nofresh; t++) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; }
-                        logcur += nofresh;
-                        tail_i1 = mi; tail_R = (unsigned)R; jumped = true;
-                    }
-                    if (jumped) { log_pos(i, R, px, py); len += R; }
-                }
+            const unsigned me = wv.l0();
+            const bool act = me < nb;
+            unsigned mi = 0, ld = 0, en = 0;
+            if (act) mi = memo[myS];
+            if (act && mi) { ld = A.logbuf[4ull * (mi - 1)]; en = A.logbuf[4ull * (mi - 1) + 2]; }
+            const bool hit_old = act && mi && ld == myS && (en != 0 || (mi - 1 >= run_begin && mi - 1 < run_begin + nofresh));
+            bool dup = false; unsigned dsrc = 0;                                             // latest earlier pending state equal to mine
+            for (unsigned jp = 0; jp + 1 < nb; jp++) { const unsigned sj = wv.bcast(myS, (int)jp); if (act && me > jp && myS == sj) { dup = true; dsrc = jp; } }
+            const int js = wv.first(hit_old || dup);
+            const unsigned ncommit = js < 0 ? nb : (unsigned)js;
+            if (logcur + nofresh + ncommit > log_cap) { over = true; nb = 0; return 2; }
+            if (me < ncommit) { const unsigned idx = run_begin + nofresh + me; A.logbuf[4ull * idx] = myS; A.logbuf[4ull * idx + 2] = 0u; memo[myS] = idx + 1; }
+            wv.fence();
+            if (js < 0) { nofresh += nb; nb = 0; return 0; }
+            // the reference would have stopped at pending state js: roll the step counter back to it
+            const unsigned ev_mi = wv.bcast(dup ? run_begin + nofresh + dsrc + 1u : mi, js), ev_en = wv.bcast(dup ? 0u : en, js);
+            nofresh += (unsigned)js;
+            steps = steps_b + (unsigned)js + 1;
+            const unsigned i = ev_mi - 1;
+            const unsigned long long R = (unsigned long long)g2 + 1ull - steps;             // points still to come until the guard fires
+            if (ev_en != 0) d_hit++; else d_det++;
+            // committed trajectory of an earlier walk: this run's own no-fresh states become a transient record that runs into entry i, so
+            // later walks can jump from them too.  A state of this very run: the cycle [i, run_begin + nofresh) is closed.
+            if (nofresh) {
+                const unsigned end = run_begin + nofresh;
+                for (unsigned t = me; t < nofresh; t += wv.nl()) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; }
+                logcur += nofresh;
+                wv.fence();
             }
-            if (jumped) break;
-            if (logcur + nofresh < log_cap) {                         // log the state (provisional until its run closes a cycle)
-                const unsigned idx = run_begin + nofresh;
-                if (wv.leader()) { A.logbuf[4ull * idx] = state; A.logbuf[4ull * idx + 2] = 0u; memo[state] = idx + 1; }
-            } else over = true;
-            nofresh++;
+            tail_i1 = ev_mi; tail_R = (unsigned)R; tail_len = R;
+            int ex, ey; log_pos(i, R, ex, ey); wv.set_cursor(ex, ey);
+            nb = 0;
+            return 1;
+        };
+        int ended = 0, kopp = 8;
+        while (true) {
+            unsigned m_any, m_unvis;
+            wv.probe(kopp, m_any, m_unvis);
+            const bool fresh = m_unvis != 0;
+            const unsigned m = fresh ? m_unvis : m_any;
+            if (!m) break;
+            if (fresh && nb) { ended = flush(); if (ended) break; }
+            const int k = ffs8(m);
+            if (!fresh && nb == 0) steps_b = steps;
+            if (steps < room) wv.put_code(slog, room, steps, k); else over = true;
+            steps++;
+            wv.step(k, fresh);
+            kopp = 7 - k;
+            if (wv.px == x0 && wv.py == y0) break;
+            if (steps > g2) break;
+            if (fresh) { nofresh = 0; continue; }
+            if (wv.l0() == nb) myS = (wv.pl << 3) | (unsigned)k;
+            nb++;
+            if (nb == nbatch) { ended = flush(); if (ended) break; }
         }
-        wv.fence();
+        if (!ended && nb) ended = flush();
+        wv.finish_codes(slog, room, steps);
+        wv.sync_marks();
+        if (ended == 2) break;
+        stepcur += steps; d_s2 += steps;
+        unsigned long long len = 1ull + steps + tail_len;
         unsigned flags = 0;
         if (len >= 2) {
-            int ddx = x0 - px, ddy = y0 - py;
+            int ddx = x0 - wv.px, ddy = y0 - wv.py;
             if (ddx * ddx + ddy * ddy < 3) { flags = 1; len++; }   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}: the start is appended again
         }
-        finish(2u * b + fg + (q - b), len >= 2 ? len : 0, n_own, sbeg, tail_i1, tail_R, flags);
+        finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
     }
     if (over && wv.leader()) *A.overflow = 1;
-    if (A.dbg && wv.leader()) { unsigned long long* d = A.dbg + 8ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg_comp; }
+    if (A.dbg && wv.leader()) { unsigned long long* d = A.dbg + 8ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg; }
 }
 
 // Points of one recorded walk (winfo slot `slot`), written by one wavefront.

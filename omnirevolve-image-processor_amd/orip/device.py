@@ -134,6 +134,12 @@ class Device:
     def find_contours(self):
         self._ck(self.L.orip_find_contours(self.h))
 
+    def contours_prepare(self):
+        self._ck(self.L.orip_contours_prepare(self.h))
+
+    def contours_layer(self, layer: int):
+        self._ck(self.L.orip_contours_layer(self.h, layer))
+
     def get_skeleton(self, layer: int) -> np.ndarray:
         out = np.empty((self.H, self.W), np.uint8)
         self._ck(self.L.orip_get_skeleton(self.h, layer, _p(out)))
@@ -193,6 +199,12 @@ class Device:
     def dedup_cross(self, order: Sequence[int], prm: _l.Params10):
         o = np.ascontiguousarray(np.asarray(list(order), np.int32))
         self._ck(self.L.orip_dedup_cross(self.h, _p(o), len(o), C.byref(prm)))
+
+    def dedup_cross_begin(self, prm: _l.Params10):
+        self._ck(self.L.orip_dedup_cross_begin(self.h, C.byref(prm)))
+
+    def dedup_cross_layer(self, layer: int):
+        self._ck(self.L.orip_dedup_cross_layer(self.h, layer))
 
     def plot_order(self, layer: int, R_insert: float) -> np.ndarray:
         n = C.c_int64(0)

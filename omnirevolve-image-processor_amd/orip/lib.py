@@ -8,6 +8,11 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "liborip.so")
 
+# One hardware queue per lane (layer pipelines, raster stages, stage 10): HIP multiplexes its streams onto GPU_MAX_HW_QUEUES
+# (default 4) hardware queues and kernels sharing a queue run one after the other, so a short kernel of one layer would wait
+# behind a long walk of another.  Must be in the environment before the HIP runtime initialises (bench.py sets it before torch).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 MAX_LAYERS = 16
 SLOT_CONTOURS, SLOT_SCALED, SLOT_SORTED, SLOT_LINES_INTRA, SLOT_LINES_CROSS = range(5)
 TAPS_INTRA, TAPS_CROSS = 0, 1
@@ -41,7 +46,8 @@ SIGNATURES = {
     "orip_keep_layers": (_i32, [_vp, _vp, _i32]),
     "orip_detect_edges": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "orip_get_edges": (_i32, [_vp, _i32, _vp]), "orip_set_edges": (_i32, [_vp, _vp, _i32, _i32, _i32]),
-    "orip_find_contours": (_i32, [_vp]), "orip_get_skeleton": (_i32, [_vp, _i32, _vp]),
+    "orip_find_contours": (_i32, [_vp]), "orip_contours_prepare": (_i32, [_vp]), "orip_contours_layer": (_i32, [_vp, _i32]),
+    "orip_dedup_cross_begin": (_i32, [_vp, _P(Params10)]), "orip_dedup_cross_layer": (_i32, [_vp, _i32]), "orip_get_skeleton": (_i32, [_vp, _i32, _vp]),
     "orip_polys_size": (_i32, [_vp, _i32, _i32, _P(_i64), _P(_i64)]), "orip_get_polys": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "orip_set_polys": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp]),
     "orip_taps_size": (_i32, [_vp, _i32, _i32, _P(_i64)]), "orip_get_taps": (_i32, [_vp, _i32, _i32, _vp]),

@@ -97,24 +97,20 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
             mine_local = list(range(len(mine)))
     else:
         mine_local = list(range(K))
+    order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
+    R = S.r_insert12(cfg)
+    if world == 1:
+        S._detect_edges_resident(dev, cfg)
+        res = S.run_layer_pipelines(dev, cfg, W, H, range(K), order, 12, lambda g: dev.plot_order(g, R))
+        return sum(len(o) for o in res.values())
     if mine_local:
         S._detect_edges_resident(dev, cfg)
-        dev.find_contours()
-        sx, sy, dx, dy = scale_factors(cfg, W, H)
-        p8 = S.params08(cfg)
-        def per_layer(l):
-            dev.scale_vectors(l, sx, sy, dx, dy)
-            dev.sort_contours(l)
-            dev.dedup_layer(l, p8)
-        S.for_each_layer(per_layer, mine_local)
-    if world > 1:
-        local = {g: (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i)) for i, g in enumerate(mine)}
-        allv = exchange_layer_lists(local, K, coll_device)
-        dev.set_layer_count(K)
-        for g in range(K):
-            dev.set_polys(_l.SLOT_LINES_INTRA, g, allv[g][0])
-            dev.set_taps(_l.TAPS_INTRA, g, allv[g][1])
-    order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
+        S.run_layer_pipelines(dev, cfg, W, H, mine_local, None, 8)
+    local = {g: (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i)) for i, g in enumerate(mine)}
+    allv = exchange_layer_lists(local, K, coll_device)
+    dev.set_layer_count(K)
+    for g in range(K):
+        dev.set_polys(_l.SLOT_LINES_INTRA, g, allv[g][0])
+        dev.set_taps(_l.TAPS_INTRA, g, allv[g][1])
     dev.dedup_cross(order, S.params10(cfg))
-    R = S.r_insert12(cfg)
-    return sum(len(o) for o in S.for_each_layer(lambda g: dev.plot_order(g, R), mine if world > 1 else range(K)))
+    return sum(len(o) for o in S.for_each_layer(lambda g: dev.plot_order(g, R), mine))

@@ -197,10 +197,15 @@ def for_each_layer(fn, layers):
     layers = list(layers)
     if len(layers) <= 1 or os.environ.get("ORIP_SERIAL_LAYERS"):      # the switch is a profiling aid: kernels of one layer at a time
         return [fn(l) for l in layers]
+    return list(_get_pool().map(fn, layers))
+
+
+def _get_pool():
+    global _pool
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(max_workers=_l.MAX_LAYERS)
-    return list(_pool.map(fn, layers))
+        _pool = ThreadPoolExecutor(max_workers=_l.MAX_LAYERS + 2)
+    return _pool
 
 
 # ---------------------------------------------------------------- the resident end-to-end path
@@ -220,24 +225,70 @@ def run_path(bgr: np.ndarray, cfg: Config, dev: Device | None = None, centers: n
     if upto < 3: return None
     _detect_edges_resident(d, cfg)
     if upto < 4: return None
-    d.find_contours()
-    if upto < 5: return None
+    if upto < 5:
+        d.find_contours()
+        return None
+    order = sorted(range(K), key=lambda l: (darkness_rank10(lnames[l]), names.index(lnames[l])))
+    R = r_insert12(cfg)
+    tail = None
+    if upto >= 12:
+        tail = (lambda l: ops_from_device(d, l, R)) if fetch_ops else (lambda l: d.plot_order(l, R))
+    res = run_layer_pipelines(d, cfg, W, H, range(K), order if upto >= 10 else None, upto, tail)
+    if upto < 12 or not fetch_ops:
+        return None
+    return {lnames[l]: res[l] for l in range(K)}
+
+
+def run_layer_pipelines(d: Device, cfg: Config, W: int, H: int, layers, order, upto: int = 12, tail=None) -> dict:
+    """Stages 04 -> 12 as one dependency-driven pipeline per layer (edges must be resident).  The reference runs stage after
+    stage over all layers (pipeline.py:17-31); the only cross-layer dependency is stage 10, which visits the layers from dark
+    to light and needs layer l's stage-08 output plus the raster painted by the layers before it (10:230-262).  So every
+    layer walks 04 -> 05 -> 07 -> 08 on its own lane (host thread + HIP stream), the calling thread feeds the layers to
+    stage 10 in `order` as they become ready, and `tail(layer)` (stage 12) runs as soon as the layer has left stage 10.
+    order None: stop after stage min(upto, 8).  Returns {layer: tail result}."""
+    import threading
+    layers = list(layers)
     sx, sy, dx, dy = scale_factors(cfg, W, H)
     p8 = params08(cfg)
+    d.contours_prepare()
 
-    def per_layer(l):          # stages 05, 07, 08 of one layer; each layer runs on its own HIP stream (lane l+1 of the context)
+    def front(l):
+        d.contours_layer(l)
         d.scale_vectors(l, sx, sy, dx, dy)
         if upto >= 7: d.sort_contours(l)
         if upto >= 8: d.dedup_layer(l, p8)
 
-    for_each_layer(per_layer, range(K))
-    if upto < 10: return None
-    order = sorted(range(K), key=lambda l: (darkness_rank10(lnames[l]), names.index(lnames[l])))
-    d.dedup_cross(order, params10(cfg))
-    if upto < 12: return None
-    R = r_insert12(cfg)
-    if not fetch_ops:
-        for_each_layer(lambda l: d.plot_order(l, R), range(K))
-        return None
-    res = for_each_layer(lambda l: ops_from_device(d, l, R), range(K))
-    return {lnames[l]: res[i] for i, l in enumerate(range(K))}
+    if order is None or os.environ.get("ORIP_SERIAL_LAYERS"):
+        for_each_layer(front, layers)
+        out = {}
+        if order is not None:
+            d.dedup_cross([l for l in order], params10(cfg))
+            if tail is not None:
+                out = dict(zip(layers, for_each_layer(tail, layers)))
+        return out
+    pool = _get_pool()
+    ready = {l: threading.Event() for l in layers}
+    errors = []
+
+    def guarded(l):
+        try:
+            front(l)
+        except BaseException as e:      # surfaced on the calling thread below
+            errors.append(e)
+        finally:
+            ready[l].set()
+
+    for l in sorted(layers, key=lambda l: order.index(l) if l in order else len(order)):
+        pool.submit(guarded, l)
+    d.dedup_cross_begin(params10(cfg))
+    tails = {}
+    for l in order:
+        if l in ready:
+            ready[l].wait()
+        if errors:
+            for e in ready.values(): e.wait()
+            raise errors[0]
+        d.dedup_cross_layer(l)
+        if tail is not None and l in ready:
+            tails[l] = pool.submit(tail, l)
+    return {l: f.result() for l, f in tails.items()}

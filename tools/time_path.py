@@ -35,3 +35,8 @@ for rep in range(2):
     total = sum(v for k, v in T.items() if k != "set_image")
     print(f"rep {rep} size {size} K {K}: contours n/pts per layer {tot}")
     print("   " + "  ".join(f"{k}={v*1e3:.1f}ms" for k, v in T.items()) + f"  | total(02-12)={total*1e3:.1f}ms -> {size*size/1e6/total:.2f} Mpx/s", flush=True)
+for rep in range(3):       # the pipelined schedule (what bench.py times): set_image excluded
+    d.set_image(img); d.sync()
+    from orip import parallel as P
+    t = time.perf_counter(); n_ops = P.run_path_sharded(d, cfg, size, size, 0, 1); d.sync(); dt = time.perf_counter() - t
+    print(f"pipelined rep {rep}: {dt*1e3:.1f} ms -> {size*size/1e6/dt:.2f} Mpx/s ({n_ops} ops)", flush=True)

@@ -1,0 +1,21 @@
+"""Timeline of the last run inside a rocprofv3 --kernel-trace CSV: dispatches after the last k_kmeans_fit launch that last
+longer than MIN_MS, by start time (development aid).  usage: python tools/trace_timeline.py <dir-or-csv> [MIN_MS]"""
+import csv, glob, os, re, sys
+p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True)
+rows = []
+for f in files:
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
+rows.sort()
+t0 = max(s for s, e, n, q, g in rows if "k_kmeans_fit" in n)
+sel = [r for r in rows if r[0] >= t0]
+end = max(e for s, e, n, q, g in sel)
+print(f"run: {(end - t0)/1e6:.1f} ms, {len(sel)} dispatches, busy kernel time {sum(e-s for s,e,n,q,g in sel)/1e6:.1f} ms")
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"void rocprim::.*::detail::", "rp::", n)
+    return n[:48]
+for s, e, n, q, g in sel:
+    if (e - s) / 1e6 >= min_ms:
+        print(f"{(s - t0)/1e6:9.2f} +{(e - s)/1e6:8.2f}  q{q:>3} grid {g:>10}  {short(n)}")
