@@ -32,17 +32,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
-def kernel_groups(H, W, K, n_points, n_skel):
-    """name -> (kernels, algorithmic bytes for ONE launch of the group's kernels, note).  DESIGN.md 'Algorithmic bytes'."""
+def kernel_groups(H, W, K, n_points):
+    """name -> (kernels, algorithmic bytes, per, note).  per == "launch": bytes of ONE launch of the (single) kernel; per == "step":
+    bytes the whole group moves in one step (its kernels run once per layer).  DESIGN.md 'Algorithmic bytes'."""
     px = H * W
     return {
-        "lab_assign": (["k_lab_assign"], 4 * px, "3 B BGR in + 1 B label out per pixel"),
-        "morph_pass": (["k_morph_pass"], 2 * K * px, "1 B in + 1 B out per pixel per layer and pass"),
-        "blur_sobel_nms": (["k_blur_sobel_nms"], 2 * K * px, "1 B mask in + 1 B NMS map out per pixel per layer"),
-        "thin_sub": (["k_thin_sub"], 2 * K * px, "1 B in + 1 B out per pixel per layer and sub-iteration"),
-        "ccl_merge": (["k_ccl_merge"], 5 * K * px, "1 B image + 4 B parent per pixel per layer"),
-        "stage04_trace": (["k_walk_count", "k_walk_write", "k_expand_cycles"], K * px + 8 * n_points,
-                          "K B/px skeleton state read once + 8 B per emitted contour point (SURVEY 8d), whole trace group"),
+        "lab_assign": (["k_lab_assign"], 4 * px, "launch", "3 B BGR in + 1 B label out per pixel"),
+        "morph_pass": (["k_morph_pass"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and pass"),
+        "blur_sobel_nms": (["k_blur_sobel_nms"], 2 * K * px, "launch", "1 B mask in + 1 B NMS map out per pixel per layer"),
+        "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration"),
+        "ccl_merge": (["k_ccl_merge"], 5 * K * px, "launch", "1 B image + 4 B parent per pixel per layer"),
+        "stage04_write": (["k_write_walks"], 8 * n_points, "step", "8 B per emitted contour point (SURVEY 8d), one launch per layer"),
+        "stage04_trace": (["k_trace", "k_write_walks"], K * px + 8 * n_points, "step",
+                          "K B/px skeleton state read once + 8 B per emitted contour point (SURVEY 8d); k_trace is a serial dependent chain "
+                          "per skeleton component (one wave each), so its time is latency, not bandwidth"),
     }
 
 
@@ -122,18 +125,18 @@ def main():
         n_points = sum(dev.polys_size(L.SLOT_CONTOURS, l)[1] for l in range(K if world == 1 else len(P.owned_layers(K, rank, world))))
         Keff = K if world == 1 else len(P.owned_layers(K, rank, world))
         best = None
-        for name, (kernels, nbytes, note) in kernel_groups(H, W, Keff, n_points, 0).items():
+        for name, (kernels, nbytes, per, note) in kernel_groups(H, W, Keff, n_points).items():
             tot_ms = 0.0; launches = 0
             for k in kernels:
                 ms, n = dev.prof_get(k); tot_ms += ms; launches = max(launches, n)
             if launches == 0:
                 continue
-            per_launch_ms = tot_ms / launches if len(kernels) == 1 else tot_ms      # groups of several kernels run once per step
-            gbs = nbytes / (per_launch_ms * 1e-3) / 1e9
-            entry = {"kernels": kernels, "launches": launches, "avg_ms": round(per_launch_ms, 4), "total_ms": round(tot_ms, 3),
-                     "algorithmic_bytes": int(nbytes), "achieved_GBs": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "note": note}
+            step_bytes = nbytes * launches if per == "launch" else nbytes
+            gbs = step_bytes / (tot_ms * 1e-3) / 1e9          # bytes of the step / summed HIP-event durations of the group's launches
+            entry = {"kernels": kernels, "launches": launches, "avg_ms": round(tot_ms / launches, 4), "total_ms": round(tot_ms, 3),
+                     "algorithmic_bytes": int(step_bytes // launches), "achieved_GBs": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5), "note": note}
             groups_out[name] = entry
-            if best is None or tot_ms > groups_out[best]["total_ms"]:
+            if name != "stage04_write" and (best is None or tot_ms > groups_out[best]["total_ms"]):
                 best = name
         if best:
             e = groups_out[best]

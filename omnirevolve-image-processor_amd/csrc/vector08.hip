@@ -94,17 +94,30 @@ __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ 
         const int64_t nseg = n - 1;
         float acc = 0.f;
         if (lane == 0) s[0] = 0.f;
-        for (int64_t base = 0; base < nseg; base += 64) {
-            int64_t k = base + lane;
-            float sl = (k < nseg) ? vs::seg_len_f32(p, k) : 0.f;
-            float pre = 0.f;
+        // four windows of 64 segment lengths per turn; the lengths of the next turn are loaded before the serial chain of this one
+        // runs, so the chain never waits for memory
+        auto load4 = [&](int64_t base, float (&sl)[4]) {
 #pragma unroll
-            for (int j = 0; j < 64; j++) {
-                float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sl), j));
-                acc = __fadd_rn(acc, v);          // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
-                pre = (lane == j) ? acc : pre;
+            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; sl[w] = (k < nseg) ? vs::seg_len_f32(p, k) : 0.f; }
+        };
+        float cur[4], nxt[4];
+        load4(0, cur);
+        for (int64_t base = 0; base < nseg; base += 256) {
+            load4(base + 256, nxt);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int64_t k = base + 64 * w + lane;
+                float pre = 0.f;
+#pragma unroll
+                for (int j = 0; j < 64; j++) {
+                    float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[w]), j));
+                    acc = __fadd_rn(acc, v);          // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
+                    pre = (lane == j) ? acc : pre;
+                }
+                if (k < nseg) s[k + 1] = pre;
             }
-            if (k < nseg) s[k + 1] = pre;
+#pragma unroll
+            for (int w = 0; w < 4; w++) cur[w] = nxt[w];
         }
         if (lane == 0) { rs_finish(r, acc, n, step); info[i] = r; }
     }
@@ -266,34 +279,81 @@ __global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, do
     long long cx = (long long)floor(__dmul_rn(A.sx[g], inv)), cy = (long long)floor(__dmul_rn(A.sy[g], inv));
     keys[g] = cell_key(A.rank[g], cx, cy); vals[g] = g;
 }
-__global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, unsigned MS, double inv, double R2,
-                                                 const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals, const unsigned* __restrict__ firstseq,
-                                                 int W, int2* __restrict__ spt, uint8_t* __restrict__ sflag) {
+// Two passes: the cheap test (own sample on the canvas, first stamp of its pixel earlier than its own pops) streams over all samples
+// and collects the survivors; the hash-bucket searches (dozens of dependent loads) then run over the dense survivor list, so a wave
+// is not held up by one lane that has to search.
+__global__ __launch_bounds__(256) void k_accept_pre(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, unsigned MS,
+                                                     const unsigned* __restrict__ firstseq, int W, int2* __restrict__ spt, uint8_t* __restrict__ sflag,
+                                                     unsigned* __restrict__ surv, unsigned* __restrict__ n_surv) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= MS) return;
-    unsigned r = A.rank[g], b = sbase[r], j = g - b;
-    double x = A.sx[g], y = A.sy[g];
-    bool ok = A.inc[g] != 0;
-    unsigned limit = b + npop[g];        // own samples with global index < limit have been popped (hashed + stamped)
-    if (ok && firstseq[(size_t)A.yi[g] * W + A.xi[g]] < limit) ok = false;
-    if (ok && npop[g] > 0) {
-        long long cx = (long long)floor(__dmul_rn(x, inv)), cy = (long long)floor(__dmul_rn(y, inv));
-        for (int dx = -1; dx <= 1 && ok; dx++)
-            for (int dy = -1; dy <= 1 && ok; dy++) {
-                unsigned long long key = cell_key(r, cx + dx, cy + dy);
-                long long lo = b, hi = sbase[r + 1];          // the sorted keys of polyline r occupy exactly its own sample range
-                const long long seg_end = hi;
-                while (lo < hi) { long long mid = (lo + hi) >> 1; if (skeys[mid] < key) lo = mid + 1; else hi = mid; }
-                for (long long q = lo; q < seg_end && skeys[q] == key; q++) {
-                    unsigned g2 = svals[q];
-                    if (g2 >= limit) break;                     // buckets are in pop order
-                    double ddx = __dsub_rn(A.sx[g2], x), ddy = __dsub_rn(A.sy[g2], y);
-                    if (__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)) <= R2) { ok = false; break; }
-                }
-            }
+    bool need = false;
+    if (g < MS) {
+        unsigned r = A.rank[g], b = sbase[r], j = g - b;
+        bool ok = A.inc[g] != 0;
+        const unsigned np = npop[g];
+        unsigned limit = b + np;         // own samples with global index < limit have been popped (hashed + stamped)
+        if (ok && firstseq[(size_t)A.yi[g] * W + A.xi[g]] < limit) ok = false;
+        spt[g] = make_int2((int)A.sx[g], (int)A.sy[g]);
+        sflag[g] = (ok ? 1 : 0) | (j == 0 ? 2 : 0);
+        need = ok && np > 0;
     }
-    spt[g] = make_int2((int)x, (int)y);
-    sflag[g] = (ok ? 1 : 0) | (j == 0 ? 2 : 0);
+    const unsigned long long m = __ballot(need);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(n_surv, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (need) surv[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = g;
+    }
+}
+// one wavefront per survivor: 65-ary lower-bound searches and 64-wide scans of the three buckets of a column (they are neighbours in
+// key order).  A bucket lists the polyline's own samples in pop order, so "popped before me" is simply g2 < limit; the reference
+// stops at the first later sample, here later samples are just not counted -- the answer (any earlier sample within R) is the same.
+__global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, double inv, double R2,
+                                                 const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals,
+                                                 const unsigned* __restrict__ surv, const unsigned* __restrict__ n_surv, uint8_t* __restrict__ sflag) {
+    const unsigned ns = *n_surv;
+    const int lane = threadIdx.x & 63;
+    for (unsigned t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ns; t += gridDim.x * 4) {
+        const unsigned g = surv[t];
+        const unsigned r = A.rank[g], b = sbase[r];
+        const double x = A.sx[g], y = A.sy[g];
+        const unsigned limit = b + npop[g];
+        const long long cx = (long long)floor(__dmul_rn(x, inv)), cy = (long long)floor(__dmul_rn(y, inv));
+        const long long seg_end = sbase[r + 1];
+        bool rej = false;
+        for (int dx = -1; dx <= 1 && !rej; dx++) {
+            const unsigned long long key_lo = cell_key(r, cx + dx, cy - 1), key_hi = cell_key(r, cx + dx, cy + 1);
+            long long lo = b, hi = seg_end;                       // first entry >= key_lo
+            while (hi - lo > 0) {
+                const long long w = (hi - lo + 64) / 65;          // 64 probes split [lo, hi) into 65 parts
+                const long long pos = lo + (long long)(lane + 1) * w - 1;
+                const bool below = pos < hi && skeys[pos] < key_lo;
+                const int cnt = __popcll(__ballot(below));        // probes are increasing: the `below` lanes are a prefix
+                const long long nlo = lo + (long long)cnt * w;
+                const long long nhi = (cnt < 64) ? min(hi, lo + (long long)(cnt + 1) * w - 1) : hi;
+                lo = min(nlo, hi); hi = nhi;
+            }
+            for (long long q = lo; q < seg_end; q += 64) {
+                const long long idx = q + lane;
+                bool in = false, hit = false;
+                if (idx < seg_end) {
+                    const unsigned long long k = skeys[idx];
+                    in = k <= key_hi;
+                    if (in) {
+                        const unsigned g2 = svals[idx];
+                        if (g2 < limit) {
+                            double ddx = __dsub_rn(A.sx[g2], x), ddy = __dsub_rn(A.sy[g2], y);
+                            hit = __dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)) <= R2;
+                        }
+                    }
+                }
+                if (__ballot(hit)) { rej = true; break; }
+                if (__ballot(in) != ~0ull) break;
+            }
+        }
+        if (rej && lane == 0) sflag[g] &= (uint8_t)~1u;
+    }
 }
 
 // ================================================================= B: _post_skeleton_merge
@@ -745,7 +805,13 @@ __global__ __launch_bounds__(256) void k_concat_taps(const int2* a, int64_t na, 
 }
 
 // split_small_and_taps on a DPolys -> kept (opened) + taps appended to tapbuf at tap_base
-int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, DBuf& tapbuf, int64_t tap_base, int64_t* n_taps_out) {
+__global__ __launch_bounds__(256) void k_compact_feat(const unsigned* __restrict__ flag, const unsigned* __restrict__ scan, int64_t n, const PolyFeat* __restrict__ in, PolyFeat* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flag[i]) out[scan[i]] = in[i];
+}
+// kept_feat (optional, room for src.n entries): features of the kept polylines' open views (bbox + numpy perimeter), so the caller
+// does not have to read the points again
+int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, DBuf& tapbuf, int64_t tap_base, int64_t* n_taps_out, PolyFeat* kept_feat = nullptr) {
     kept.n = 0; kept.total = 0; *n_taps_out = 0;
     HIPC(c, kept.off.ensure(64)); HIPC(c, hipMemsetAsync(kept.off.p, 0, 8, LN(c).stream));
     int64_t n = src.n;
@@ -755,7 +821,7 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     int2* tap_xy = (int2*)(keep_scan + (n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (n + 1)); GatherDesc* kd2 = kd + (n + 1);
     HIPC(c, LN(c).vtmp[10].ensure((size_t)n * sizeof(PolyFeat) + 64));
     PolyFeat* sfeat = LN(c).vtmp[10].as<PolyFeat>();
-    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, 0, sfeat));
+    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, kept_feat ? (1 | 16) : 0, sfeat));
     { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, sfeat, is_tap, is_keep, tap_xy, kd); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
@@ -769,6 +835,7 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     if (nk) {
         hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, n, kd, kd2, (const int2*)nullptr, (int2*)nullptr);
         ORIP_TRY(vgather(c, kd2, nk, src.pts.as<int32_t>(), kept));
+        if (kept_feat) hipLaunchKernelGGL(k_compact_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, n, sfeat, kept_feat);
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -806,15 +873,14 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         snprintf(b, sizeof b, " %s %.2f", name, std::chrono::duration<double, std::milli>(t - tprev).count()); tlog += b; tprev = t;
     };
     // ---- A0
-    ORIP_TRY(split_small(c, S, P, kept0.p, TOUT.xy, 0, &nt0));
+    HIPC(c, LN(c).vtmp[6].ensure((size_t)S.n * sizeof(PolyFeat) + 64));
+    PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();       // open-view features of the kept polylines (perimeter: A1)
+    ORIP_TRY(split_small(c, S, P, kept0.p, TOUT.xy, 0, &nt0, feat));
     const int64_t nk = kept0.p.n;
     tick("split");
     if (nk > 0) {
         if (kept0.p.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
         // ---- A1: order by perimeter, descending, stable
-        HIPC(c, LN(c).vtmp[6].ensure((size_t)nk * sizeof(PolyFeat) + 64));
-        PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
-        ORIP_TRY(vfeatures(c, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, kept0.p.total, 1, feat));
         tick("feat");
         HIPC(c, LN(c).vtmp[0].ensure((size_t)nk * 16 + (size_t)(nk + 1) * 8 + (size_t)nk * sizeof(RsInfo) + 256));
         float* kin = LN(c).vtmp[0].as<float>(); float* kout = kin + nk; unsigned* vin = (unsigned*)(kout + nk); unsigned* ord = vin + nk;
@@ -867,7 +933,14 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             { ProfScope ps(c, "sort_cells"); ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cvin, cvout, (size_t)MS, 0, 32 + rbits))); }
             tick("cells");
             // ---- A6
-            { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, inv, P.col_rad * P.col_rad, ckout, cvout, firstseq, W, spt, sflag); }
+            {
+                unsigned* surv = reinterpret_cast<unsigned*>(ckin);              // the unsorted keys are no longer needed
+                unsigned* d_ns = LN(c).flags.as<unsigned>() + 60;
+                HIPC(c, hipMemsetAsync(d_ns, 0, 4, LN(c).stream));
+                ProfScope ps(c, "k_accept");
+                hipLaunchKernelGGL(k_accept_pre, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, firstseq, W, spt, sflag, surv, d_ns);
+                hipLaunchKernelGGL(k_accept, dim3((unsigned)std::min<unsigned>(cdiv(MS, 256), 16384u)), dim3(256), 0, LN(c).stream, A, sbase, npop, inv, P.col_rad * P.col_rad, ckout, cvout, surv, d_ns, sflag);
+            }
             HIPC(c, hipGetLastError());
             tick("accept");
             ORIP_TRY(orip_runs_to_polys(c, spt, sflag, MS, cleaned.p));
