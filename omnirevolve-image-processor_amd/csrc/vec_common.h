@@ -279,6 +279,18 @@ __global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict
         __syncthreads();
     }
 }
+// minimum of a 64-bit key over the wavefront with DPP row shifts / broadcasts (no LDS round trips); every lane gets the result
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v) {
+#define ORIP_DPP_MIN(ctrl, rmask) { \
+        unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(unsigned)v, ctrl, rmask, 0xf, false); \
+        unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(unsigned)(v >> 32), ctrl, rmask, 0xf, false); \
+        unsigned long long t_ = ((unsigned long long)hi_ << 32) | lo_; if (t_ < v) v = t_; }
+    ORIP_DPP_MIN(0x111, 0xf) ORIP_DPP_MIN(0x112, 0xf) ORIP_DPP_MIN(0x114, 0xf) ORIP_DPP_MIN(0x118, 0xf)      // row_shr 1, 2, 4, 8
+    ORIP_DPP_MIN(0x142, 0xa) ORIP_DPP_MIN(0x143, 0xc)                                                          // row_bcast 15, 31
+#undef ORIP_DPP_MIN
+    unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), rh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)rh << 32) | rl;
+}
 // Grid-pruned variant (same selection rule, same tie-break, n <= 11000 or so and int16 coordinates): the entry points (start of
 // every polyline, end of every polyline that may be entered reversed) are bucketed into a G x G grid held in LDS next to the end
 // points.  A greedy step scans the (2r+1)^2 cells around the cursor, r = 1, 3, 7, ...; it is final as soon as the best squared
@@ -305,12 +317,13 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     for (int i = lane; i <= G * G; i += 64) cst[i] = 0;
     __syncthreads();
     const int ox = mnx, oy = mny;
-    const int cs = max(1, (max(mxx - mnx, mxy - mny) + G) / G);                     // (coord - origin) / cs < G for every end point
+    int sh = 0; while (((max(mxx - mnx, mxy - mny)) >> sh) >= G) sh++;                // power-of-two cells: (coord - origin) >> sh < G for every end point
+    const int cs = 1 << sh;
     // ---- counting sort of the entries by cell
     for (int i = lane; i < n; i += 64) {
         short4 e = P[i];
-        atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u);
-        if (!(stt[i] & 2)) atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u);
+        atomicAdd(&cst[((e.y - oy) >> sh) * G + ((e.x - ox) >> sh)], 1u);
+        if (!(stt[i] & 2)) atomicAdd(&cst[((e.w - oy) >> sh) * G + ((e.z - ox) >> sh)], 1u);
     }
     __syncthreads();
     {   // exclusive scan of the G*G counts: a run of consecutive cells per lane
@@ -326,8 +339,8 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     __syncthreads();
     for (int i = lane; i < n; i += 64) {         // scatter; cst[c] ends up as the END of cell c, i.e. start(c) = c ? cst[c-1] : 0
         short4 e = P[i];
-        Eid[atomicAdd(&cst[((e.y - oy) / cs) * G + (e.x - ox) / cs], 1u)] = (uint16_t)(i << 1);
-        if (!(stt[i] & 2)) Eid[atomicAdd(&cst[((e.w - oy) / cs) * G + (e.z - ox) / cs], 1u)] = (uint16_t)((i << 1) | 1);
+        Eid[atomicAdd(&cst[((e.y - oy) >> sh) * G + ((e.x - ox) >> sh)], 1u)] = (uint16_t)(i << 1);
+        if (!(stt[i] & 2)) Eid[atomicAdd(&cst[((e.w - oy) >> sh) * G + ((e.z - ox) >> sh)], 1u)] = (uint16_t)((i << 1) | 1);
     }
     int cx, cy;
     { short4 e = P[seed]; if (stt[seed] & 2) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; } }
@@ -336,25 +349,37 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     int prev = seed;
     unsigned long long d_rounds = 0, d_scanned = 0, d_full = 0;
     for (int step = 1; step < n; step++) {
-        const int gx = (cx - ox) / cs, gy = (cy - oy) / cs;
+        const int gx = (cx - ox) >> sh, gy = (cy - oy) >> sh;
         unsigned long long best = ~0ULL;
         for (int r = 1;; r = 2 * r + 1) {
             const int x0 = max(0, gx - r), x1 = min(G - 1, gx + r), y0 = max(0, gy - r), y1 = min(G - 1, gy + r);
             unsigned long long mine = ~0ULL;
+            auto consider = [&](unsigned q) {
+                const unsigned id = Eid[q]; const int i = (int)(id >> 1);
+                const uint8_t f = stt[i]; const short4 e = P[i];
+                if ((f & 1) || i == prev) return;
+                float v = (id & 1) ? nn_d2(e.z, e.w, cx, cy) : nn_d2(e.x, e.y, cx, cy);
+                unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
+                if (key < mine) mine = key;
+            };
+            if (y1 - y0 <= 2) {
+                // up to three rows: lanes 0..2 fetch the entry ranges of the rows, then all lanes share the concatenated entries
+                unsigned lo_l = 0, n_l = 0;
+                if (lane <= y1 - y0) { const int c0 = (y0 + lane) * G + x0, c1 = (y0 + lane) * G + x1; lo_l = c0 ? cst[c0 - 1] : 0u; n_l = cst[c1] - lo_l; }
+                const unsigned lo0 = (unsigned)__builtin_amdgcn_readlane((int)lo_l, 0), n0 = (unsigned)__builtin_amdgcn_readlane((int)n_l, 0);
+                const unsigned lo1 = (unsigned)__builtin_amdgcn_readlane((int)lo_l, 1), n1 = (unsigned)__builtin_amdgcn_readlane((int)n_l, 1);
+                const unsigned lo2 = (unsigned)__builtin_amdgcn_readlane((int)lo_l, 2), n2 = (unsigned)__builtin_amdgcn_readlane((int)n_l, 2);
+                const unsigned total = n0 + n1 + n2;
+                if (dbg) d_scanned += total;
+                for (unsigned t = lane; t < total; t += 64) consider(t < n0 ? lo0 + t : (t - n0 < n1 ? lo1 + (t - n0) : lo2 + (t - n0 - n1)));
+            } else
             for (int row = y0; row <= y1; row++) {
                 const int c0 = row * G + x0, c1 = row * G + x1;
                 const unsigned lo = c0 ? cst[c0 - 1] : 0u, hi = cst[c1];
                 if (dbg) d_scanned += hi - lo;
-                for (unsigned q = lo + lane; q < hi; q += 64) {
-                    const unsigned id = Eid[q]; const int i = (int)(id >> 1);
-                    if ((stt[i] & 1) || i == prev) continue;
-                    short4 e = P[i];
-                    float v = (id & 1) ? nn_d2(e.z, e.w, cx, cy) : nn_d2(e.x, e.y, cx, cy);
-                    unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
-                    if (key < mine) mine = key;
-                }
+                for (unsigned q = lo + lane; q < hi; q += 64) consider(q);
             }
-            for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(mine, o, 64); if (t < mine) mine = t; }
+            mine = wave_min_key(mine);
             best = mine;
             if (dbg) d_rounds++;
             if (x0 == 0 && y0 == 0 && x1 == G - 1 && y1 == G - 1) { if (dbg) d_full++; break; }     // everything scanned

@@ -181,9 +181,10 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A, unsigned* __restrict__ npop) {
+__global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A, unsigned* __restrict__ npop, const unsigned* __restrict__ only) {
     const int lane = threadIdx.x;
     for (int64_t r = blockIdx.x; r < n_rank; r += gridDim.x) {
+        if (only && !only[r]) continue;       // only the polylines the parallel version could not decide
         const unsigned b = sbase[r], e = sbase[r + 1];
         if (e <= b) continue;
         const double* D = A.dprev + b; unsigned* NP = npop + b;
@@ -210,6 +211,34 @@ __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sb
         }
         if (jw + lane < m) NP[jw + lane] = nv;
     }
+}
+// Parallel form of the same simulation.  After sample j is pushed the queue holds samples head..j and tail_len is the sum of the
+// distances D[head+1..j]; the pops leave the smallest head with that sum <= tail_len_px (the sums shrink as head grows and a head
+// never moves back because D >= 0).  With S = per-polyline inclusive prefix sums of D (rocPRIM scan-by-key) the sum is S[j] - S[head],
+// found by binary search.  The reference compares a float64 running sum with its own rounding history; both that sum and S[j]-S[h]
+// are within ~1e-8 px of the real sum for polylines shorter than 2^22 px (ulp(2^22) * <64 additions per scan path; 2 ulp(256) per
+// push/pop over < 2^20 samples), so a comparison that clears the threshold by more than ORIP_TAIL_EPS is the reference's decision.
+// Any sample that is closer marks its polyline, and marked polylines are redone by the sequential k_tail_sim.
+#define ORIP_TAIL_EPS 1e-6
+__global__ __launch_bounds__(256) void k_tail_par(const unsigned* __restrict__ sbase, const unsigned* __restrict__ rank, const double* __restrict__ S, unsigned MS, double T,
+                                                   unsigned* __restrict__ npop, unsigned* __restrict__ redo) {
+    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= MS) return;
+    const unsigned r = rank[g], b = sbase[r];
+    const double Sj = S[g];
+    bool unsure = !(Sj < 4194304.0) || (g - b) >= (1u << 20);
+    // smallest h in [b, g] with Sj - S[h] <= T; gallop back from g (the tail covers a few dozen samples), then bisect
+    unsigned lo = b, hi = g;                 // answer in [lo, hi]; S[hi] satisfies (Sj - S[g] = 0 <= T)
+    for (unsigned stepb = 1; hi > b; stepb <<= 1) {
+        const unsigned p = (hi - b > stepb) ? hi - stepb : b;
+        if (Sj - S[p] <= T) { hi = p; if (p == b) break; } else { lo = p + 1; break; }
+    }
+    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (Sj - S[mid] <= T) hi = mid; else lo = mid + 1; }
+    const unsigned h = lo;
+    if (!(Sj - S[h] <= T - ORIP_TAIL_EPS)) unsure = true;
+    if (h > b && !(Sj - S[h - 1] > T + ORIP_TAIL_EPS)) unsure = true;
+    npop[g] = h - b;
+    if (unsure) redo[r] = 1u;
 }
 // previous in-canvas sample of the same polyline (the far end of the capsule stamped when sample j is popped, 08:151-155); -1: none, -2: j is off-canvas
 __global__ __launch_bounds__(256) void k_capprev(const unsigned* __restrict__ sbase, unsigned MS, SampleArrs A, int* __restrict__ capprev) {
@@ -909,7 +938,20 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
-            { ProfScope ps(c, "k_tail_sim"); hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop); }
+            {
+                HIPC(c, LN(c).vtmp[8].ensure((size_t)MS * 8 + (size_t)(nk + 1) * 4 + 64));
+                double* S = LN(c).vtmp[8].as<double>(); unsigned* redo = (unsigned*)(S + MS);
+                HIPC(c, hipMemsetAsync(redo, 0, (size_t)(nk + 1) * 4, LN(c).stream));
+                size_t bytes = 0;
+                HIPC(c, rocprim::inclusive_scan_by_key(nullptr, bytes, A.rank, A.dprev, S, (size_t)MS, rocprim::plus<double>(), rocprim::equal_to<unsigned>(), LN(c).stream));
+                HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+                HIPC(c, rocprim::inclusive_scan_by_key(LN(c).tmpF.p, bytes, A.rank, A.dprev, S, (size_t)MS, rocprim::plus<double>(), rocprim::equal_to<unsigned>(), LN(c).stream));
+                ProfScope ps(c, "k_tail_sim");
+                hipLaunchKernelGGL(k_tail_par, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, A.rank, S, MS, P.tail_len_px, npop, redo);
+                if (getenv("ORIP_TAIL_DBG")) { std::vector<unsigned> h(nk), sb(nk + 1); hipStreamSynchronize(LN(c).stream); hipMemcpy(h.data(), redo, nk * 4, hipMemcpyDeviceToHost); hipMemcpy(sb.data(), sbase, (nk + 1) * 4, hipMemcpyDeviceToHost); unsigned long long nf = 0, sf = 0, mx = 0; for (int64_t q = 0; q < nk; q++) if (h[q]) { nf++; sf += sb[q + 1] - sb[q]; mx = std::max<unsigned long long>(mx, sb[q + 1] - sb[q]); } fprintf(stderr, "[tail dbg] layer %d: %llu of %lld polylines redone, %llu of %u samples, longest redone %llu\n", layer, nf, (long long)nk, sf, MS, mx); }
+                const unsigned* only = getenv("ORIP_TAIL_SEQ") ? nullptr : redo;          // test hook: force the sequential simulation everywhere
+                hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop, only);
+            }
             hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, capprev);
             tick("tail");
             // ---- A4: de-duplicated capsules -> min-sequence canvas

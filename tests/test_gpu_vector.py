@@ -193,6 +193,30 @@ def test_stage08_component_size_classes(dev, monkeypatch):
         assert same_polys(got_l, want_l), (caps, len(got_l), len(want_l))
 
 
+def test_stage08_tail_simulation_both_forms(dev, monkeypatch):
+    """The tail simulation runs in a parallel form (prefix sums + a margin test) with the sequential float64 recurrence as its
+    fallback; forcing the fallback everywhere must give the same lines (and both must match the oracle)."""
+    from orip import stages as S
+    rng = np.random.default_rng(77)
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=10)
+    cfg = _cfgobj(cfgd)
+    W, H = O.canvas_size(cfgd)
+    polys = []
+    for _ in range(40):
+        m = int(rng.integers(20, 400))
+        p = (np.cumsum(rng.integers(-9, 10, (m, 2)), axis=0) + rng.integers(100, min(W, H) - 100, 2)).astype(np.int32)
+        polys.append(np.concatenate([p, p[::-1], p]).reshape(-1, 1, 2))       # retraced paths: the tail rule decides what survives
+    want_l, want_t = O.stage08_layer(polys, O.derived08(cfgd))
+    for seq in [False, True]:
+        if seq:
+            monkeypatch.setenv("ORIP_TAIL_SEQ", "1")
+        else:
+            monkeypatch.delenv("ORIP_TAIL_SEQ", raising=False)
+        got_l, got_t = S.dedup_layer(polys, cfg, dev)
+        assert got_t == want_t, seq
+        assert same_polys(got_l, want_l), (seq, len(got_l), len(want_l))
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_full_chain_image_to_ops_matches_reference(dev, tag):
     """Resident path 02 -> 12 from the image: final ops identical to the reference chain's ops.pkl."""
