@@ -19,6 +19,8 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
     for (auto& l : c->ln) {
         if (hipStreamCreate(&l.stream) != hipSuccess) { delete c; return -5; }
         hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
+        if (hipStreamCreate(&l.stream2) != hipSuccess) { delete c; return -5; }
+        hipEventCreateWithFlags(&l.ev2, hipEventDisableTiming); hipEventCreateWithFlags(&l.ev3, hipEventDisableTiming);
         if (l.flags.ensure(4096) != hipSuccess) { delete c; return -6; }
         hipMemsetAsync(l.flags.p, 0, 4096, l.stream);
         hipStreamSynchronize(l.stream);
@@ -38,6 +40,9 @@ extern "C" void orip_destroy(orip_ctx* c) {
         for (auto& v : l.vtmp) v.release();
         if (l.ev0) hipEventDestroy(l.ev0);
         if (l.ev1) hipEventDestroy(l.ev1);
+        if (l.ev2) hipEventDestroy(l.ev2);
+        if (l.ev3) hipEventDestroy(l.ev3);
+        if (l.stream2) hipStreamDestroy(l.stream2);
         if (l.stream) hipStreamDestroy(l.stream);
     }
     for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); }

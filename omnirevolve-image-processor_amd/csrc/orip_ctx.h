@@ -64,6 +64,8 @@ struct ProfEntry { double ms = 0; int64_t launches = 0; };
 // each on its own HIP stream with its own scratch (the serial kernels of one layer then overlap with those of the others).
 struct LaneRes {
     hipStream_t stream = 0;
+    hipStream_t stream2 = 0;              // side stream of the lane (work that may overlap the main chain), fenced with ev2 / ev3
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
     DBuf vtmp[12], tmpE, tmpF, flags, canvas;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DPolys tp[6];   // persistent temporaries of the vector stages (no hipFree in steady state: hipFree synchronises the device)

@@ -241,14 +241,18 @@ __global__ __launch_bounds__(256) void k_tail_par(const unsigned* __restrict__ s
     if (unsure) redo[r] = 1u;
 }
 // previous in-canvas sample of the same polyline (the far end of the capsule stamped when sample j is popped, 08:151-155); -1: none, -2: j is off-canvas
-__global__ __launch_bounds__(256) void k_capprev(const unsigned* __restrict__ sbase, unsigned MS, SampleArrs A, int* __restrict__ capprev) {
+// lastin[g] = 1 + index of the last in-canvas sample at or before g inside its polyline (0: none): a max-scan by polyline
+struct IncIndex {
+    const uint8_t* inc;
+    __device__ unsigned operator()(unsigned g) const { return inc[g] ? g + 1u : 0u; }
+};
+__global__ __launch_bounds__(256) void k_capprev(const unsigned* __restrict__ sbase, unsigned MS, SampleArrs A, const unsigned* __restrict__ lastin, int* __restrict__ capprev) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     if (!A.inc[g]) { capprev[g] = -2; return; }
     const unsigned b = sbase[A.rank[g]];
-    int p = -1;
-    for (unsigned q = g; q > b; ) { q--; if (A.inc[q]) { p = (int)(q - b); break; } }
-    capprev[g] = p;
+    const unsigned l = g > b ? lastin[g - 1] : 0u;
+    capprev[g] = l ? (int)(l - 1u - b) : -1;
 }
 
 // ================================================================= A4: capsule de-duplication + min-sequence stamping
@@ -259,7 +263,7 @@ __device__ __forceinline__ unsigned long long cap_key(int x0, int y0, int x1, in
 }
 __device__ __forceinline__ unsigned long long hash64(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigned* __restrict__ sbase, const int* __restrict__ capprev, unsigned MS,
-                                                      unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tvals, unsigned long long tmask) {
+                                                      unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tvals, unsigned long long tmask, int max_probe, int* __restrict__ overflow) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     int cp = capprev[g];
@@ -267,10 +271,11 @@ __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigne
     unsigned b = sbase[A.rank[g]];
     unsigned long long key = cap_key(A.xi[b + cp], A.yi[b + cp], A.xi[g], A.yi[g]);
     unsigned long long h = hash64(key) & tmask;
-    while (true) {
+    for (int probe = 0;; probe++) {
+        if (probe >= max_probe) { *overflow = 1; return; }      // table too small for the number of distinct capsules: the host retries larger
         unsigned long long cur = tkeys[h];
         if (cur == 0) { unsigned long long old = atomicCAS(&tkeys[h], 0ULL, key); if (old == 0 || old == key) cur = key; else cur = old; }
-        if (cur == key) { atomicMin(&tvals[h], g); return; }
+        if (cur == key) { if (*(volatile unsigned*)&tvals[h] > g) atomicMin(&tvals[h], g); return; }    // the minimum only decreases: a stale read can only cost a useless atomic
         h = (h + 1) & tmask;
     }
 }
@@ -299,14 +304,16 @@ __global__ __launch_bounds__(256) void k_caps_stamp(const unsigned long long* __
 }
 
 // ================================================================= A5: _PointHash.near (08:85-93)
-__device__ __forceinline__ unsigned long long cell_key(unsigned r, long long cx, long long cy) {
-    return ((unsigned long long)r << 32) | ((unsigned long long)((cx + 32768) & 0xffff) << 16) | (unsigned long long)((cy + 32768) & 0xffff);
+// The samples of a polyline are contiguous (rank-major), so the hash of a polyline is its own sample range sorted by cell: a
+// segmented sort on the 32-bit cell key (column, row).  The sort is stable, so every bucket lists its samples in pop order.
+__device__ __forceinline__ unsigned cell_key(long long cx, long long cy) {
+    return ((unsigned)((cx + 32768) & 0xffff) << 16) | (unsigned)((cy + 32768) & 0xffff);
 }
-__global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, double inv, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, double inv, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     long long cx = (long long)floor(__dmul_rn(A.sx[g], inv)), cy = (long long)floor(__dmul_rn(A.sy[g], inv));
-    keys[g] = cell_key(A.rank[g], cx, cy); vals[g] = g;
+    keys[g] = cell_key(cx, cy); vals[g] = g;
 }
 // Two passes: the cheap test (own sample on the canvas, first stamp of its pixel earlier than its own pops) streams over all samples
 // and collects the survivors; the hash-bucket searches (dozens of dependent loads) then run over the dense survivor list, so a wave
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void k_accept_pre(SampleArrs A, const unsigned
 // key order).  A bucket lists the polyline's own samples in pop order, so "popped before me" is simply g2 < limit; the reference
 // stops at the first later sample, here later samples are just not counted -- the answer (any earlier sample within R) is the same.
 __global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, double inv, double R2,
-                                                 const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals,
+                                                 const unsigned* __restrict__ skeys, const unsigned* __restrict__ svals,
                                                  const unsigned* __restrict__ surv, const unsigned* __restrict__ n_surv, uint8_t* __restrict__ sflag) {
     const unsigned ns = *n_surv;
     const int lane = threadIdx.x & 63;
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __
         const long long seg_end = sbase[r + 1];
         bool rej = false;
         for (int dx = -1; dx <= 1 && !rej; dx++) {
-            const unsigned long long key_lo = cell_key(r, cx + dx, cy - 1), key_hi = cell_key(r, cx + dx, cy + 1);
+            const unsigned key_lo = cell_key(cx + dx, cy - 1), key_hi = cell_key(cx + dx, cy + 1);
             long long lo = b, hi = seg_end;                       // first entry >= key_lo
             while (hi - lo > 0) {
                 const long long w = (hi - lo + 64) / 65;          // 64 probes split [lo, hi) into 65 parts
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256) void k_accept(SampleArrs A, const unsigned* __
                 const long long idx = q + lane;
                 bool in = false, hit = false;
                 if (idx < seg_end) {
-                    const unsigned long long k = skeys[idx];
+                    const unsigned k = skeys[idx];
                     in = k <= key_hi;
                     if (in) {
                         const unsigned g2 = svals[idx];
@@ -950,33 +957,64 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 hipLaunchKernelGGL(k_tail_par, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, A.rank, S, MS, P.tail_len_px, npop, redo);
                 if (getenv("ORIP_TAIL_DBG")) { std::vector<unsigned> h(nk), sb(nk + 1); hipStreamSynchronize(LN(c).stream); hipMemcpy(h.data(), redo, nk * 4, hipMemcpyDeviceToHost); hipMemcpy(sb.data(), sbase, (nk + 1) * 4, hipMemcpyDeviceToHost); unsigned long long nf = 0, sf = 0, mx = 0; for (int64_t q = 0; q < nk; q++) if (h[q]) { nf++; sf += sb[q + 1] - sb[q]; mx = std::max<unsigned long long>(mx, sb[q + 1] - sb[q]); } fprintf(stderr, "[tail dbg] layer %d: %llu of %lld polylines redone, %llu of %u samples, longest redone %llu\n", layer, nf, (long long)nk, sf, MS, mx); }
                 const unsigned* only = getenv("ORIP_TAIL_SEQ") ? nullptr : redo;          // test hook: force the sequential simulation everywhere
-                hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream, sbase, nk, P.tail_len_px, A, npop, only);
+                // the sequential redo only feeds the acceptance test (A6): it runs on the lane's side stream under the capsule / hash work
+                HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));
+                HIPC(c, hipStreamWaitEvent(LN(c).stream2, LN(c).ev2, 0));
+                hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
+                HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream2));
             }
-            hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, capprev);
+            {
+                HIPC(c, LN(c).vtmp[8].ensure((size_t)MS * 8 + (size_t)(nk + 1) * 4 + 64));
+                unsigned* lastin = LN(c).vtmp[8].as<unsigned>();            // the prefix sums of the tail simulation are no longer needed
+                auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned>(0u), IncIndex{A.inc});
+                size_t bytes = 0;
+                HIPC(c, rocprim::inclusive_scan_by_key(nullptr, bytes, A.rank, vin, lastin, (size_t)MS, rocprim::maximum<unsigned>(), rocprim::equal_to<unsigned>(), LN(c).stream));
+                HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+                HIPC(c, rocprim::inclusive_scan_by_key(LN(c).tmpF.p, bytes, A.rank, vin, lastin, (size_t)MS, rocprim::maximum<unsigned>(), rocprim::equal_to<unsigned>(), LN(c).stream));
+                hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, lastin, capprev);
+            }
             tick("tail");
             // ---- A4: de-duplicated capsules -> min-sequence canvas
             HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
             unsigned* firstseq = LN(c).canvas.as<unsigned>();
             HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
-            unsigned long long tsize = 1024; while (tsize < 2ull * MS) tsize <<= 1;
-            HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 12 + 64));
-            unsigned long long* tkeys = LN(c).vtmp[4].as<unsigned long long>(); unsigned* tvals = (unsigned*)(tkeys + tsize);
-            HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, LN(c).stream));
-            HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, LN(c).stream));
-            { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1); }
+            // The table only has to hold the DISTINCT capsules (retraced paths repeat theirs many times), which is not known in advance:
+            // start at a quarter of the sample count with bounded probing and grow on overflow; 2 * MS slots always suffice.
+            unsigned long long tfull = 1024; while (tfull < 2ull * MS) tfull <<= 1;
+            unsigned long long tsize = 1024; while (tsize < MS / 4ull) tsize <<= 1;
+            if (getenv("ORIP_CAPS_TINY")) tsize = 1024;            // test hook: exercise the growth path
+            unsigned long long* tkeys = nullptr; unsigned* tvals = nullptr;
+            int* d_ovf = LN(c).flags.as<int>() + 62;
+            for (;; tsize = std::min(tfull, tsize * 4)) {
+                HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 12 + 64));
+                tkeys = LN(c).vtmp[4].as<unsigned long long>(); tvals = (unsigned*)(tkeys + tsize);
+                HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, LN(c).stream));
+                HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, LN(c).stream));
+                HIPC(c, hipMemsetAsync(d_ovf, 0, 4, LN(c).stream));
+                const int max_probe = tsize >= tfull ? 0x7fffffff : 96;
+                { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1, max_probe, d_ovf); }
+                int ovf = 0; ORIP_TRY(vread(c, &ovf, d_ovf));
+                if (!ovf) break;
+            }
             { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
             tick("caps");
             // ---- A5: (polyline, cell) buckets in pop order
             HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
-            unsigned long long* ckin = LN(c).vtmp[5].as<unsigned long long>(); unsigned long long* ckout = ckin + MS; unsigned* cvin = (unsigned*)(ckout + MS); unsigned* cvout = cvin + MS;
+            unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
             hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, MS, inv, ckin, cvin);
-            int rbits = 1; while ((1ll << rbits) < nk + 1) rbits++;
-            { ProfScope ps(c, "sort_cells"); ORIP_TRY((vsort_pairs<unsigned long long, unsigned>(c, ckin, ckout, cvin, cvout, (size_t)MS, 0, 32 + rbits))); }
+            {
+                ProfScope ps(c, "sort_cells");
+                size_t bytes = 0;
+                HIPC(c, rocprim::segmented_radix_sort_pairs(nullptr, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
+                HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+                HIPC(c, rocprim::segmented_radix_sort_pairs(LN(c).tmpF.p, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
+            }
             tick("cells");
             // ---- A6
             {
-                unsigned* surv = reinterpret_cast<unsigned*>(ckin);              // the unsorted keys are no longer needed
+                HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));       // pop counts of the redone polylines
+                unsigned* surv = ckin;                                           // the unsorted keys are no longer needed
                 unsigned* d_ns = LN(c).flags.as<unsigned>() + 60;
                 HIPC(c, hipMemsetAsync(d_ns, 0, 4, LN(c).stream));
                 ProfScope ps(c, "k_accept");

@@ -210,6 +210,7 @@ def test_stage08_tail_simulation_both_forms(dev, monkeypatch):
     for seq in [False, True]:
         if seq:
             monkeypatch.setenv("ORIP_TAIL_SEQ", "1")
+            monkeypatch.setenv("ORIP_CAPS_TINY", "1")      # and the capsule table starts too small: growth path
         else:
             monkeypatch.delenv("ORIP_TAIL_SEQ", raising=False)
         got_l, got_t = S.dedup_layer(polys, cfg, dev)
