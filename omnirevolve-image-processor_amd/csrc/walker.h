@@ -63,7 +63,7 @@ struct WalkArgs {
 };
 
 #ifndef ORIP_WALK_BATCH
-#define ORIP_WALK_BATCH 64u     // pending no-fresh states looked up together (at most one per lane)
+#define ORIP_WALK_BATCH 4u      // first look-up of a no-fresh run after this many pending states; the batch then doubles (at most one state per lane)
 #endif
 namespace walk_detail {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -301,7 +301,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     // pending state that is already known (to an older record, to this run, or to an earlier pending state) ends the walk there and
     // the steps taken after it are dropped; otherwise all of them become provisional entries of this run.
     const unsigned g2 = fg * 4u;                                  // guard of a leftover walk (04:199)
-    const unsigned nbatch = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
+    const unsigned nbatch0 = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
     for (unsigned q = wv.scan(A.lin, b, e, ST_FG); q < e && !over; q = wv.scan(A.lin, q + 1, e, ST_FG)) {
         unsigned s = A.lin[q];
         const int x0 = (int)(s % W), y0 = (int)(s / W);
@@ -315,6 +315,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         unsigned long long tail_len = 0; unsigned tail_i1 = 0, tail_R = 0;
         unsigned nofresh = 0;                 // no-fresh states logged since the last fresh pixel: entries [run_begin, run_begin + nofresh)
         unsigned nb = 0, myS = 0, steps_b = 0;                     // pending states; steps before the first of them
+        unsigned nbatch = nbatch0;                                 // memo hits come early in a run or not for a while: 4, 8, 16, ... pending states per look-up
         // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow
         auto flush = [&]() -> int {
             if (!nb) return 0;
@@ -369,10 +370,10 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             kopp = 7 - k;
             if (wv.px == x0 && wv.py == y0) break;
             if (steps > g2) break;
-            if (fresh) { nofresh = 0; continue; }
+            if (fresh) { nofresh = 0; nbatch = nbatch0; continue; }
             if (wv.l0() == nb) myS = (wv.pl << 3) | (unsigned)k;
             nb++;
-            if (nb == nbatch) { ended = flush(); if (ended) break; }
+            if (nb == nbatch) { ended = flush(); if (ended) break; nbatch = nbatch * 2u < wv.nl() ? nbatch * 2u : wv.nl(); }
         }
         if (!ended && nb) ended = flush();
         wv.finish_codes(slog, room, steps);
