@@ -102,6 +102,11 @@ struct Wave {
     __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
     // lane 0 loads, everybody gets the value
     __device__ unsigned ld0(const unsigned* p) const { unsigned v = 0; if (lane == 0) v = *p; return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+    // one 16-byte record (state, cont, end, begin) with a single load
+    __device__ void ld0_rec(const unsigned* p, unsigned& cont, unsigned& en, unsigned& begin) const {
+        uint4 v = make_uint4(0, 0, 0, 0); if (lane == 0) v = *reinterpret_cast<const uint4*>(p);
+        cont = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y); en = (unsigned)__builtin_amdgcn_readfirstlane((int)v.z); begin = (unsigned)__builtin_amdgcn_readfirstlane((int)v.w);
+    }
     __device__ void flush_marks() {
         if (nm) { if (lane < nm) { const unsigned e = mlist[lane]; st[e >> 4] = (u8)(e & 15u); } nm = 0; }
     }
@@ -193,6 +198,7 @@ struct Wave {
     unsigned nl() const { return 1u; }
     void fence() const {}
     unsigned ld0(const unsigned* p) const { return *p; }
+    void ld0_rec(const unsigned* p, unsigned& cont, unsigned& en, unsigned& begin) const { cont = p[1]; en = p[2]; begin = p[3]; }
     void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; }
     void mark_cursor(u8 v) { st[pl] = (u8)(v | ST_VIS); }
     void sync_marks() {}
@@ -234,7 +240,7 @@ ORIP_HD inline int nby(int k) { return (int)((0xA940u >> (2 * k)) & 3u) - 1; }
 template <class WaveT>
 ORIP_HD inline unsigned long long log_resolve(const unsigned* logbuf, const WaveT& wv, unsigned rec, unsigned long long f) {
     while (true) {
-        const unsigned cont = wv.ld0(&logbuf[4ull * rec + 1]), en = wv.ld0(&logbuf[4ull * rec + 2]), begin = wv.ld0(&logbuf[4ull * rec + 3]);
+        unsigned cont, en, begin; wv.ld0_rec(&logbuf[4ull * rec], cont, en, begin);
         if (f < en) return f;
         if (cont >= begin) return (unsigned long long)cont + (f - en) % (unsigned long long)(en - cont);   // cycle
         f = (unsigned long long)cont + (f - en); rec = cont;                                               // transient -> older record
@@ -332,8 +338,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             const unsigned ncommit = js < 0 ? nb : (unsigned)js;
             if (logcur + nofresh + ncommit > log_cap) { over = true; nb = 0; return 2; }
             if (me < ncommit) { const unsigned idx = run_begin + nofresh + me; A.logbuf[4ull * idx] = myS; A.logbuf[4ull * idx + 2] = 0u; memo[myS] = idx + 1; }
-            wv.fence();
-            if (js < 0) { nofresh += nb; nb = 0; return 0; }
+            if (js < 0) { wv.fence(); nofresh += nb; nb = 0; return 0; }
             // the reference would have stopped at pending state js: roll the step counter back to it
             const unsigned ev_mi = wv.bcast(dup ? run_begin + nofresh + dsrc + 1u : mi, js), ev_en = wv.bcast(dup ? 0u : en, js);
             nofresh += (unsigned)js;
@@ -347,8 +352,8 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
                 const unsigned end = run_begin + nofresh;
                 for (unsigned t = me; t < nofresh; t += wv.nl()) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; }
                 logcur += nofresh;
-                wv.fence();
             }
+            wv.fence();                                       // provisional entries and the record are in memory before anything reads the log
             tail_i1 = ev_mi; tail_R = (unsigned)R; tail_len = R;
             int ex, ey; log_pos(i, R, ex, ey); wv.set_cursor(ex, ey);
             nb = 0;
