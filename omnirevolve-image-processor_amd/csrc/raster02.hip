@@ -351,6 +351,249 @@ __global__ __launch_bounds__(KM_T) void k_kmeans_fit(const u8* __restrict__ data
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same fit spread over KMB_B workgroups with a device-wide barrier between phases (the single workgroup above spends 13 ms
+// of pure ALU time on one CU at the head of the whole path).  Every workgroup executes the same control flow: all decisions
+// are taken from values that every block reads from global memory after a barrier.  Integer sums are order-free; the only
+// floating-point reduction (compactness) is still evaluated by workgroup 0 with the tree of the 1024-thread version.
+// ------------------------------------------------------------------------------------------------
+#define KMB_B 64
+#define KMB_T 256
+struct KmGlobal {
+    unsigned bar_count, bar_gen;
+    long long acc[8];                              // rotating accumulators of the integer passes
+    long long tot[2][ORIP_MAX_LAYERS * 4];         // cluster sums (L, a, b, count), double-buffered by iteration parity
+    unsigned long long key;                        // farthest-point search of the empty-cluster repair
+    int ci;
+    double compact;
+    float slow_centers[ORIP_MAX_LAYERS * 3];
+    long long blockpart[KMB_B];
+};
+__device__ __forceinline__ void km_grid_sync(KmGlobal* G) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = atomicAdd(&G->bar_gen, 0u);
+        if (atomicAdd(&G->bar_count, 1u) == KMB_B - 1) { atomicExch(&G->bar_count, 0u); __threadfence(); atomicAdd(&G->bar_gen, 1u); }
+        else while (atomicAdd(&G->bar_gen, 0u) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __threadfence();
+}
+__device__ __forceinline__ long long kmb_block_sum(long long v, long long* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long r = 0;
+    for (int w = 0; w < KMB_T / 64; w++) r += red[w];
+    return r;
+}
+__global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ data, int N, int K, int attempts, int maxCount, double epsilon,
+                                                          int32_t* __restrict__ dist0, int32_t* __restrict__ dist1, int32_t* __restrict__ dist2, int32_t* __restrict__ labels,
+                                                          double* __restrict__ dd, long long* __restrict__ parts, float* __restrict__ centers_out,
+                                                          double* __restrict__ compact_out, int* __restrict__ status, KmGlobal* __restrict__ G) {
+    __shared__ long long red[KMB_T / 64];
+    __shared__ float centers[ORIP_MAX_LAYERS * 3], old_centers[ORIP_MAX_LAYERS * 3];
+    __shared__ int csum[KMB_T / 64][ORIP_MAX_LAYERS * 4];
+    __shared__ long long tot[ORIP_MAX_LAYERS * 4];
+    __shared__ int pp_idx[ORIP_MAX_LAYERS];
+    __shared__ double sh_shift;
+    __shared__ double ptree[1024];
+    const int tid = threadIdx.x, wave = tid >> 6, bid = blockIdx.x;
+    const int gtid = bid * KMB_T + tid, gsz = KMB_B * KMB_T;
+    const int chunk = (N + gsz - 1) / gsz;
+    const int lo = min(N, gtid * chunk), hi = min(N, lo + chunk);
+    unsigned long long rng = 0xffffffffULL;   // identical in every thread
+    double best_compact = 1.79769313486231570815e+308;
+    int32_t *dist = dist0, *tdist = dist1, *tdist2 = dist2;
+    unsigned pass = 0;                        // selects the accumulator; slot pass+4 is cleared for later use
+    // grid-wide integer sum of v (one value per thread); two barriers apart accumulators never collide
+    auto grid_sum = [&](long long v) -> long long {
+        long long bs = kmb_block_sum(v, red);
+        const unsigned slot = pass & 7u;
+        if (tid == 0) { atomicAdd((unsigned long long*)&G->acc[slot], (unsigned long long)bs); if (bid == 0) G->acc[(pass + 4u) & 7u] = 0; }
+        km_grid_sync(G);
+        long long r = *(volatile long long*)&G->acc[slot];
+        pass++;
+        return r;
+    };
+    for (int a = 0; a < attempts; a++) {
+        double compactness = 0;
+        for (int iter = 0;;) {
+            double max_shift = iter == 0 ? 1.79769313486231570815e+308 : 0.0;
+            __syncthreads();
+            if (tid < K * 3) { float t = centers[tid]; centers[tid] = old_centers[tid]; old_centers[tid] = t; }
+            __syncthreads();
+            if (iter == 0) {
+                // ---------------- generateCentersPP ----------------
+                if (bid == 0 && tid < 2 * ORIP_MAX_LAYERS * 4) (&G->tot[0][0])[tid] = 0;     // both sum buffers start an attempt empty (barriers follow)
+                int c0 = (int)(km_next(rng) % (unsigned)N);
+                if (tid == 0) pp_idx[0] = c0;
+                long long ls = 0;
+                for (int i = gtid; i < N; i += gsz) { int d = isq3(data + 3 * i, data + 3 * c0); dist[i] = d; ls += d; }
+                long long sum0 = grid_sum(ls);
+                for (int k = 1; k < K; k++) {
+                    long long bestSum = 0x7fffffffffffffffLL; int bestCenter = -1;
+                    for (int j = 0; j < 3; j++) {
+                        double p = km_double(rng) * (double)sum0;
+                        // ci = first index with inclusive prefix >= p, else N-1: contiguous chunk per thread, block totals, then one thread descends
+                        long long cs = 0;
+                        for (int i = lo; i < hi; i++) cs += dist[i];
+                        parts[gtid] = cs;
+                        long long bs = kmb_block_sum(cs, red);
+                        if (tid == 0) G->blockpart[bid] = bs;
+                        km_grid_sync(G);
+                        if (bid == 0 && tid == 0) {
+                            long long run = 0; int ci = N - 1; int b;
+                            for (b = 0; b < KMB_B; b++) { long long v = *(volatile long long*)&G->blockpart[b]; if ((double)(run + v) >= p) break; run += v; }
+                            if (b < KMB_B) {
+                                int t;
+                                for (t = 0; t < KMB_T; t++) { long long v = *(volatile long long*)&parts[b * KMB_T + t]; if ((double)(run + v) >= p) break; run += v; }
+                                if (t < KMB_T) {
+                                    int l2 = min(N, (b * KMB_T + t) * chunk), h2 = min(N, l2 + chunk);
+                                    for (int i = l2; i < h2; i++) { run += dist[i]; if ((double)run >= p) { ci = i; break; } }
+                                }
+                            }
+                            if (ci > N - 1) ci = N - 1;
+                            G->ci = ci;
+                        }
+                        km_grid_sync(G);
+                        const int ci = *(volatile int*)&G->ci;
+                        long long s = 0;
+                        for (int i = gtid; i < N; i += gsz) { int d = min(isq3(data + 3 * i, data + 3 * ci), dist[i]); tdist2[i] = d; s += d; }
+                        long long S = grid_sum(s);
+                        if (S < bestSum) { bestSum = S; bestCenter = ci; int32_t* t = tdist; tdist = tdist2; tdist2 = t; }
+                    }
+                    if (tid == 0) pp_idx[k] = bestCenter;
+                    sum0 = bestSum;
+                    { int32_t* t = dist; dist = tdist; tdist = t; }
+                    __syncthreads();
+                }
+                __syncthreads();
+                if (tid < K * 3) centers[tid] = (float)data[3 * pp_idx[tid / 3] + tid % 3];
+                __syncthreads();
+            } else {
+                // ---------------- recompute centres from labels ----------------
+                const int par = iter & 1;
+                for (int i = tid; i < (KMB_T / 64) * ORIP_MAX_LAYERS * 4; i += KMB_T) (&csum[0][0])[i] = 0;
+                __syncthreads();
+                for (int i = gtid; i < N; i += gsz) {
+                    int k = labels[i];
+                    atomicAdd(&csum[wave][k * 4 + 0], (int)data[3 * i]);
+                    atomicAdd(&csum[wave][k * 4 + 1], (int)data[3 * i + 1]);
+                    atomicAdd(&csum[wave][k * 4 + 2], (int)data[3 * i + 2]);
+                    atomicAdd(&csum[wave][k * 4 + 3], 1);
+                }
+                __syncthreads();
+                if (tid < K * 4) {
+                    long long t = 0; for (int w = 0; w < KMB_T / 64; w++) t += csum[w][tid];
+                    atomicAdd((unsigned long long*)&G->tot[par][tid], (unsigned long long)t);
+                    if (bid == 0) G->tot[par ^ 1][tid] = 0;        // the other buffer was last read two barriers ago
+                }
+                if (bid == 0 && tid == 0) G->key = 0;
+                km_grid_sync(G);
+                if (tid < K * 4) tot[tid] = *(volatile long long*)&G->tot[par][tid];
+                __syncthreads();
+                // float accumulation in sample order is exact (== integer sum) while every partial sum < 2^24
+                bool bad = false;
+                for (int k = 0; k < K; k++) for (int j = 0; j < 3; j++) if (tot[k * 4 + j] >= (1LL << 24)) bad = true;
+                if (bad) {
+                    // rare slow path: literal sequential float32 accumulation by one lane
+                    if (bid == 0 && tid == 0) {
+                        float acc[ORIP_MAX_LAYERS * 3];
+                        for (int q = 0; q < K * 3; q++) acc[q] = 0.f;
+                        for (int i = 0; i < N; i++) { int k = labels[i]; for (int j = 0; j < 3; j++) acc[k * 3 + j] = __fadd_rn(acc[k * 3 + j], (float)data[3 * i + j]); }
+                        for (int q = 0; q < K * 3; q++) G->slow_centers[q] = acc[q];
+                    }
+                    km_grid_sync(G);
+                    if (tid < K * 3) centers[tid] = *(volatile float*)&G->slow_centers[tid];
+                } else if (tid < K * 3) centers[tid] = (float)tot[(tid / 3) * 4 + tid % 3];
+                __syncthreads();
+                // empty-cluster repair (sequential over k, as the reference)
+                for (int k = 0; k < K; k++) {
+                    if (tot[k * 4 + 3] != 0) continue;      // uniform: every block holds the same totals
+                    int max_k = 0;
+                    for (int k1 = 1; k1 < K; k1++) if (tot[max_k * 4 + 3] < tot[k1 * 4 + 3]) max_k = k1;
+                    float nb[3]; float scale = 1.f / (float)tot[max_k * 4 + 3];
+                    for (int j = 0; j < 3; j++) nb[j] = __fmul_rn(centers[max_k * 3 + j], scale);
+                    // farthest point: max_dist <= dist  => last index among maxima
+                    unsigned long long key = 0;
+                    for (int i = gtid; i < N; i += gsz) {
+                        if (labels[i] != max_k) continue;
+                        float d = fsq3(data + 3 * i, nb);
+                        unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+                        if (kk >= key) key = kk;
+                    }
+                    atomicMax(&G->key, key);
+                    km_grid_sync(G);
+                    const int far_i = (int)(*(volatile unsigned long long*)&G->key & 0xffffffffu);
+                    __syncthreads();
+                    if (tid == 0) {
+                        tot[max_k * 4 + 3]--; tot[k * 4 + 3]++;
+                        if (bid == 0) labels[far_i] = k;
+                        for (int j = 0; j < 3; j++) {
+                            float v = (float)data[3 * far_i + j];
+                            centers[max_k * 3 + j] = __fsub_rn(centers[max_k * 3 + j], v);
+                            centers[k * 3 + j] = __fadd_rn(centers[k * 3 + j], v);
+                        }
+                    }
+                    km_grid_sync(G);                           // everybody has read the key before it is cleared
+                    if (bid == 0 && tid == 0) G->key = 0;
+                    km_grid_sync(G);
+                }
+                if (tid == 0) {
+                    for (int k = 0; k < K; k++) {
+                        float scale = 1.f / (float)tot[k * 4 + 3];
+                        for (int j = 0; j < 3; j++) centers[k * 3 + j] = __fmul_rn(centers[k * 3 + j], scale);
+                        if (iter > 0) {
+                            double d = 0;
+                            for (int j = 0; j < 3; j++) { double t = (double)__fsub_rn(centers[k * 3 + j], old_centers[k * 3 + j]); d = __dadd_rn(d, __dmul_rn(t, t)); }
+                            max_shift = fmax(max_shift, d);
+                        }
+                    }
+                    sh_shift = max_shift;
+                }
+                __syncthreads();
+                max_shift = sh_shift;
+                __syncthreads();
+            }
+            ++iter;
+            bool last = (iter == max(maxCount, 2)) || (max_shift <= epsilon);
+            if (last) {
+                for (int i = gtid; i < N; i += gsz) dd[i] = (double)fsq3(data + 3 * i, &centers[3 * labels[i]]);
+                km_grid_sync(G);
+                if (bid == 0) {
+                    // the reduction tree of the 1024-thread version: strided partials, shfl_down tree per 64, then 16 sequential adds
+                    for (int v = tid; v < 1024; v += KMB_T) { double s = 0; for (int i = v; i < N; i += 1024) s += dd[i]; ptree[v] = s; }
+                    __syncthreads();
+                    for (int o = 32; o > 0; o >>= 1) {
+                        for (int q = tid; q < 16 * o; q += KMB_T) { const int w = q / o, l = q % o; ptree[w * 64 + l] += ptree[w * 64 + l + o]; }
+                        __syncthreads();
+                    }
+                    if (tid == 0) { double r = 0; for (int w = 0; w < 16; w++) r += ptree[w * 64]; G->compact = r; }
+                }
+                km_grid_sync(G);
+                compactness = *(volatile double*)&G->compact;
+                break;
+            } else {
+                for (int i = gtid; i < N; i += gsz) {
+                    float md = 0.f; int kb = 0;
+                    for (int k = 0; k < K; k++) { float d = fsq3(data + 3 * i, &centers[3 * k]); if (k == 0 || md > d) { md = d; kb = k; } }
+                    labels[i] = kb;
+                }
+                km_grid_sync(G);
+            }
+        }
+        if (compactness < best_compact) {
+            best_compact = compactness;
+            if (bid == 0 && tid < K * 3) centers_out[tid] = centers[tid];
+        }
+        __syncthreads();
+    }
+    if (bid == 0 && tid == 0) { *compact_out = best_compact; *status = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Morphology: one erode/dilate pass with a k x k structuring element given as a bit mask (bit i*k+j).
 // Out-of-image neighbours never win (cv2 default border).  If labels_mode, the source is the label
 // map and the pixel value is (label == layer) ? 255 : 0  -- fuses `mask=(labels==k)*255` (02:150).
@@ -482,10 +725,17 @@ extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n
     double* d_comp = (double*)((char*)LN(c).flags.p + 512);
     int* d_status = (int*)LN(c).flags.p;
     HIPC(c, hipMemsetAsync(LN(c).flags.p, 0xff, 4, LN(c).stream));
-    {
+    if (getenv("ORIP_KMEANS_1WG")) {          // the single-workgroup version (test hook: both must give the same centres)
         ProfScope ps(c, "k_kmeans_fit");
         hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
                            base, base + N, base + 2 * N, base + 3 * N, d_centers, d_comp, d_status);
+    } else {
+        HIPC(c, c->tmpA.ensure((size_t)N * 8 + (size_t)KMB_B * KMB_T * 8 + sizeof(KmGlobal) + 256));
+        double* dd = c->tmpA.as<double>(); long long* parts = (long long*)(dd + N); KmGlobal* G = (KmGlobal*)(parts + KMB_B * KMB_T);
+        HIPC(c, hipMemsetAsync(G, 0, sizeof(KmGlobal), LN(c).stream));
+        ProfScope ps(c, "k_kmeans_fit");
+        hipLaunchKernelGGL(k_kmeans_fit_mb, dim3(KMB_B), dim3(KMB_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
+                           base, base + N, base + 2 * N, base + 3 * N, dd, parts, d_centers, d_comp, d_status, G);
     }
     HIPC(c, hipGetLastError());
     struct { float cen[ORIP_MAX_LAYERS * 3]; } hc; double comp; int st;

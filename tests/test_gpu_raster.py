@@ -57,6 +57,25 @@ def test_kmeans_random_pixels_matches_oracle(dev):
     assert np.array_equal(got, want)
 
 
+def test_kmeans_both_kernels_agree(dev, monkeypatch):
+    """The fit runs spread over 64 workgroups with a device-wide barrier; the single-workgroup version it replaced is kept
+    behind ORIP_KMEANS_1WG.  Same centres and the same compactness (fixed reduction tree), also with a cluster that empties."""
+    rng = np.random.default_rng(11)
+    for img, K in [(rng.integers(0, 256, (120, 150, 3), dtype=np.uint8), 7),
+                   (np.repeat(rng.integers(0, 256, (3, 1, 3), dtype=np.uint8), 4000, axis=1).reshape(100, 120, 3), 6)]:
+        dev.set_image(np.ascontiguousarray(img))
+        monkeypatch.delenv("ORIP_KMEANS_1WG", raising=False)
+        a, ca = dev.kmeans_fit(None, K)
+        monkeypatch.setenv("ORIP_KMEANS_1WG", "1")
+        b, cb = dev.kmeans_fit(None, K)
+        monkeypatch.delenv("ORIP_KMEANS_1WG", raising=False)
+        assert np.array_equal(a, b)
+        assert ca == cb
+        lab = O.bgr2lab(np.ascontiguousarray(img)).reshape(-1, 3).astype(np.float32)
+        want, _ = O.kmeans(lab, K)
+        assert np.array_equal(a, want)
+
+
 @pytest.mark.parametrize("case", [(128, 128, 4, None), (255, 193, 8, 4.0), (512, 512, 8, None), (64, 1030, 3, 2.0)])
 def test_stage02_labels_and_masks(dev, case):
     H, W, K, sigma = case
