@@ -79,7 +79,7 @@ __global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict
 // Evaluates numpy's pairwise tree below the node (s0, n0) from the leaf sums; `part`/`depth_left` let the root traversal stop at
 // nodes that other threads have already reduced (code = path bits from the root).
 __device__ float pairwise_subtree(const float* __restrict__ leafsum, int64_t s0, int64_t n0, const float* part, int depth_left) {
-    int64_t fs[48], fn[48]; int fstate[48], fdep[48]; unsigned fcode[48]; float fleft[48];
+    int64_t fs[28], fn[28]; int fstate[28], fdep[28]; unsigned fcode[28]; float fleft[28];     // depth <= log2(2^31 / 64) + 2
     int sp = 1; fs[0] = s0; fn[0] = n0; fstate[0] = 0; fdep[0] = depth_left; fcode[0] = 0;
     float ret = 0.f;
     while (sp > 0) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
                                                              PolyFeat* __restrict__ out, float* __restrict__ leafbuf) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
-    __shared__ float part[1 << ORIP_PW_DEPTH];
+    __shared__ float part[2 << ORIP_PW_DEPTH];
     for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
         PolyFeat f = out[i];
         const int64_t n = f.n;                     // already the open view when requested
@@ -149,17 +149,31 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
             }
             __threadfence_block();
             __syncthreads();
-            {   // thread t reduces the subtree reached by the ORIP_PW_DEPTH path bits of t (idle when the path ends in a leaf earlier)
-                int64_t s = 0, len = ns; bool mine = true;
-                for (int lvl = ORIP_PW_DEPTH - 1; lvl >= 0; lvl--) {
-                    if (len <= 128) { mine = false; break; }
+            // numpy's tree, level by level.  Node `code` (heap numbering, root 1) at depth d is reached by the d path bits of code - 2^d
+            // (0 = left half of n2 = n/2 - (n/2)%8 elements).  Depth ORIP_PW_DEPTH: thread t reduces the subtree below its node from
+            // the leaf sums; the levels above combine left + right in LDS, a node that is itself a leaf takes its leaf sum.
+            auto node_of = [&](int d, int t, int64_t& s, int64_t& len) -> bool {      // false: an ancestor is already a leaf
+                s = 0; len = ns;
+                for (int lvl = d - 1; lvl >= 0; lvl--) {
+                    if (len <= 128) return false;
                     int64_t n2 = len / 2; n2 -= n2 % 8;
-                    if ((tid >> lvl) & 1) { s += n2; len -= n2; } else len = n2;
+                    if ((t >> lvl) & 1) { s += n2; len -= n2; } else len = n2;
                 }
-                if (mine) part[tid] = pairwise_subtree(ls, s, len, nullptr, 0);
+                return true;
+            };
+            {
+                int64_t s, len;
+                if (node_of(ORIP_PW_DEPTH, tid, s, len)) part[(1 << ORIP_PW_DEPTH) + tid] = pairwise_subtree(ls, s, len, nullptr, 0);
+            }
+            for (int d = ORIP_PW_DEPTH - 1; d >= 0; d--) {
+                __syncthreads();
+                if (tid < (1 << d)) {
+                    int64_t s, len; const int code = (1 << d) + tid;
+                    if (node_of(d, tid, s, len)) part[code] = (len <= 128) ? ls[(s + 63) >> 6] : part[2 * code] + part[2 * code + 1];
+                }
             }
             __syncthreads();
-            if (tid == 0) per = pairwise_subtree(ls, 0, ns, part, ORIP_PW_DEPTH);
+            if (tid == 0) per = part[1];
         }
         if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; }
         __syncthreads();
