@@ -119,6 +119,9 @@ int orip_dedup_cross(orip_ctx* ctx, const int32_t* order, int n_layers, const or
 /* The same loop one layer at a time (10:230-262): begin clears the cumulative raster, then the layers must be passed in `order`. */
 int orip_dedup_cross_begin(orip_ctx* ctx, const orip_params10* prm);
 int orip_dedup_cross_layer(orip_ctx* ctx, int layer);
+/* same, reading LINES/TAPS_INTRA of slot `src_layer` and writing LINES/TAPS_CROSS of `layer` (layer-sharded processes keep their
+ * own layers under local indices and stage remote ones in a spare slot) */
+int orip_dedup_cross_layer_from(orip_ctx* ctx, int src_layer, int layer);
 /* ---- stage 12: _build_ops_for_layer (12:85-187): LINES/TAPS_CROSS -> ops ----
  * ops are returned as 5 int32 each: (type 0 line / 1 tap, line index into LINES_CROSS, flip, x, y). */
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);

@@ -342,7 +342,10 @@ extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
     return 0;
 }
 
-extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) {
+// input lists from layer slot `src_layer` (LINES/TAPS_INTRA), output and reporting under `layer`: lets a process that holds its own
+// layers under local indices feed stage 10 in global layer order (multi-GPU layer sharding)
+extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer) {
+    if (src_layer < 0 || src_layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", src_layer);
     if (!c->p10_ready) ORIP_FAIL(c, "orip_dedup_cross_begin has not run");
     const orip_params10 P = c->p10;
     const int W = P.W, H = P.H;
@@ -361,8 +364,8 @@ extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) {
 
         auto t0 = tdbg ? now() : std::chrono::steady_clock::time_point();
         if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
-        DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
-        DTaps& Tin = c->taps[ORIP_TAPS_INTRA][layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
+        DPolys& Lin = c->polys[ORIP_SLOT_LINES_INTRA][src_layer]; DPolys& Lout = c->polys[ORIP_SLOT_LINES_CROSS][layer];
+        DTaps& Tin = c->taps[ORIP_TAPS_INTRA][src_layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
         // ---- 1) cut
         DPolys& cut = LN(c).tp[4]; DPolys& keepl = LN(c).tp[5];   // persistent temporaries of this lane
         cut.n = 0; cut.total = 0;
@@ -444,6 +447,8 @@ extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) {
     }
     return 0;
 }
+
+extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) { return orip_dedup_cross_layer_from(c, layer, layer); }
 
 extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers, const orip_params10* prm) {
     if (!prm || n_layers < 0 || n_layers > ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");

@@ -203,8 +203,11 @@ class Device:
     def dedup_cross_begin(self, prm: _l.Params10):
         self._ck(self.L.orip_dedup_cross_begin(self.h, C.byref(prm)))
 
-    def dedup_cross_layer(self, layer: int):
-        self._ck(self.L.orip_dedup_cross_layer(self.h, layer))
+    def dedup_cross_layer(self, layer: int, src_layer: int | None = None):
+        if src_layer is None:
+            self._ck(self.L.orip_dedup_cross_layer(self.h, layer))
+        else:
+            self._ck(self.L.orip_dedup_cross_layer_from(self.h, src_layer, layer))
 
     def plot_order(self, layer: int, R_insert: float) -> np.ndarray:
         n = C.c_int64(0)

@@ -6,7 +6,8 @@ mask morphology through stage 08 every layer is independent (03:45, 04:234, 05:1
 cluster layers {l : l % world == r}.  Stage 10 walks the layers dark->light against ONE cumulative raster
 (10:215,236-267) -- the only real exchange step of the path: the per-layer (lines_intra, taps_intra) lists are
 all-gathered (RCCL all_gather over xGMI with backend "nccl"; gloo in the CPU tests), stage 10 is then replicated on
-every rank (deterministic), and each rank orders (stage 12) the layers it owns.
+every rank (deterministic), and each rank orders (stage 12) the layers it owns.  run_path_sharded streams that exchange
+layer by layer (broadcast_layer) so that stage 10 overlaps the per-layer pipelines; exchange_layer_lists is the one-shot form.
 """
 from __future__ import annotations
 
@@ -77,40 +78,87 @@ def exchange_layer_lists(local: Dict[int, Lists], K: int, device=None) -> Dict[i
     return unpack_layers(sizes, payloads, K, world)
 
 
+def broadcast_layer(lists, owner: int, device=None) -> Lists:
+    """One layer's (lines, taps) from rank `owner` to everybody: a [3] size row, then one int32 payload.  `lists` is only read
+    on the owner.  Collective: every rank calls it for the same layers in the same order."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return lists
+    rank = dist.get_rank()
+    dev = torch.device(device if device is not None else "cpu")
+    meta = np.zeros(3, np.int64); payload = np.zeros(0, np.int32)
+    if rank == owner:
+        sizes, payload = pack_layers({0: lists}, 1)
+        meta = sizes[0].copy()
+    t_meta = torch.from_numpy(meta).to(dev)
+    dist.broadcast(t_meta, src=owner)
+    meta = t_meta.cpu().numpy()
+    n = int(meta[0] + 2 * meta[1] + 2 * meta[2])
+    buf = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    if rank == owner and n:
+        buf[:n] = torch.from_numpy(payload).to(dev)
+    dist.broadcast(buf, src=owner)
+    if rank == owner:
+        return lists
+    return unpack_layers(meta.reshape(1, 3), [buf[:n].cpu().numpy()], 1, 1)[0]
+
+
 def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None):
-    """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  Ops stay on the GPU."""
+    """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  Ops stay on the GPU.
+
+    world > 1: every rank pipelines its own layers (04 -> 08, one lane each).  Stage 10 is replicated and streamed: the
+    layers are visited dark -> light; the owner of the next layer waits for its pipeline, broadcasts the layer's
+    (lines_intra, taps_intra) and everybody cuts it against the shared raster.  So, as on one GPU, stage 10 of the early
+    layers runs underneath the 04-08 work of the heavy ones, and a layer's stage 12 starts as soon as it has left stage 10."""
     from . import lib as _l
     from . import stages as S
-    from .config import scale_factors
 
     names = list(cfg.color_names)
     K = max(2, len(names))
     lnames = S.cluster_names(cfg)[:K]
     centers, _ = dev.kmeans_fit(S.subsample_indices(H * W), K)
     dev.extract_layers(centers, want_counts=False)
-    mine = owned_layers(K, rank, world)
-    if world > 1:
-        if not mine:
-            mine_local = []
-        else:
-            dev.keep_layers(mine)
-            mine_local = list(range(len(mine)))
-    else:
-        mine_local = list(range(K))
     order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
     R = S.r_insert12(cfg)
     if world == 1:
         S._detect_edges_resident(dev, cfg)
         res = S.run_layer_pipelines(dev, cfg, W, H, range(K), order, 12, lambda g: dev.plot_order(g, R))
         return sum(len(o) for o in res.values())
-    if mine_local:
+    mine = owned_layers(K, rank, world)              # global layer ids; held under local indices 0..len(mine)-1
+    ready, errors = {}, []
+    if mine:
+        dev.keep_layers(mine)
         S._detect_edges_resident(dev, cfg)
-        S.run_layer_pipelines(dev, cfg, W, H, mine_local, None, 8)
-    local = {g: (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i)) for i, g in enumerate(mine)}
-    allv = exchange_layer_lists(local, K, coll_device)
-    dev.set_layer_count(K)
-    for g in range(K):
-        dev.set_polys(_l.SLOT_LINES_INTRA, g, allv[g][0])
-        dev.set_taps(_l.TAPS_INTRA, g, allv[g][1])
-    dev.dedup_cross(order, S.params10(cfg))
-    return sum(len(o) for o in S.for_each_layer(lambda g: dev.plot_order(g, R), mine))
+        dev.contours_prepare()
+        order_local = [mine.index(g) for g in order if g in mine]
+        ready, errors = S._start_fronts(S.layer_front(dev, cfg, W, H, 8), range(len(mine)), order_local)
+    pool = S._get_pool()
+    dev.dedup_cross_begin(S.params10(cfg))
+    stage_slot = _l.MAX_LAYERS - 1                   # remote layers pass through this spare slot (len(mine) <= MAX_LAYERS / 2)
+    tails = []
+    for g in order:
+        owner = g % world
+        if owner == rank:
+            i = mine.index(g)
+            ready[i].wait()
+            failed = bool(errors)
+            lists = ([], []) if failed else (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i))
+            broadcast_layer(lists, owner, coll_device)      # the other ranks are waiting in this collective: never skip it
+            if failed:
+                continue
+            dev.dedup_cross_layer(g, src_layer=i)
+            tails.append(pool.submit(dev.plot_order, g, R))
+        else:
+            lines, taps = broadcast_layer(None, owner, coll_device)
+            dev.set_polys(_l.SLOT_LINES_INTRA, stage_slot, lines)
+            dev.set_taps(_l.TAPS_INTRA, stage_slot, taps)
+            dev.dedup_cross_layer(g, src_layer=stage_slot)
+    n_ops = sum(len(f.result()) for f in tails)
+    if errors:
+        for e in ready.values():
+            e.wait()
+        raise errors[0]
+    return n_ops

@@ -246,18 +246,9 @@ def run_layer_pipelines(d: Device, cfg: Config, W: int, H: int, layers, order, u
     layer walks 04 -> 05 -> 07 -> 08 on its own lane (host thread + HIP stream), the calling thread feeds the layers to
     stage 10 in `order` as they become ready, and `tail(layer)` (stage 12) runs as soon as the layer has left stage 10.
     order None: stop after stage min(upto, 8).  Returns {layer: tail result}."""
-    import threading
     layers = list(layers)
-    sx, sy, dx, dy = scale_factors(cfg, W, H)
-    p8 = params08(cfg)
     d.contours_prepare()
-
-    def front(l):
-        d.contours_layer(l)
-        d.scale_vectors(l, sx, sy, dx, dy)
-        if upto >= 7: d.sort_contours(l)
-        if upto >= 8: d.dedup_layer(l, p8)
-
+    front = layer_front(d, cfg, W, H, upto)
     if order is None or os.environ.get("ORIP_SERIAL_LAYERS"):
         for_each_layer(front, layers)
         out = {}
@@ -266,20 +257,8 @@ def run_layer_pipelines(d: Device, cfg: Config, W: int, H: int, layers, order, u
             if tail is not None:
                 out = dict(zip(layers, for_each_layer(tail, layers)))
         return out
+    ready, errors = _start_fronts(front, layers, order)
     pool = _get_pool()
-    ready = {l: threading.Event() for l in layers}
-    errors = []
-
-    def guarded(l):
-        try:
-            front(l)
-        except BaseException as e:      # surfaced on the calling thread below
-            errors.append(e)
-        finally:
-            ready[l].set()
-
-    for l in sorted(layers, key=lambda l: order.index(l) if l in order else len(order)):
-        pool.submit(guarded, l)
     d.dedup_cross_begin(params10(cfg))
     tails = {}
     for l in order:
@@ -292,3 +271,38 @@ def run_layer_pipelines(d: Device, cfg: Config, W: int, H: int, layers, order, u
         if tail is not None and l in ready:
             tails[l] = pool.submit(tail, l)
     return {l: f.result() for l, f in tails.items()}
+
+
+def _start_fronts(front, layers, order=None):
+    """Submit front(layer) for every layer to the pool (layers that stage 10 visits first go first).  Returns
+    ({layer: Event set when the layer is done or failed}, [exceptions])."""
+    import threading
+    pool = _get_pool()
+    ready = {l: threading.Event() for l in layers}
+    errors = []
+
+    def guarded(l):
+        try:
+            front(l)
+        except BaseException as e:      # surfaced on the calling thread
+            errors.append(e)
+        finally:
+            ready[l].set()
+
+    rank_of = (lambda l: order.index(l) if l in order else len(order)) if order else (lambda l: 0)
+    for l in sorted(layers, key=rank_of):
+        pool.submit(guarded, l)
+    return ready, errors
+
+
+def layer_front(d: Device, cfg: Config, W: int, H: int, upto: int = 8):
+    """front(layer): stages 04 (walks of the layer) -> 05 -> 07 -> 08 on the layer's lane; needs d.contours_prepare() first."""
+    sx, sy, dx, dy = scale_factors(cfg, W, H)
+    p8 = params08(cfg)
+
+    def front(l):
+        d.contours_layer(l)
+        d.scale_vectors(l, sx, sy, dx, dy)
+        if upto >= 7: d.sort_contours(l)
+        if upto >= 8: d.dedup_layer(l, p8)
+    return front

@@ -41,6 +41,38 @@ def _worker(rank, world, port, K, q):
     q.put((rank, bool(ok)))
 
 
+def _worker_stream(rank, world, port, K, q):
+    """The streamed form used by run_path_sharded: layers visited in a fixed order, the owner broadcasts each one."""
+    sys.path.insert(0, os.path.join(ROOT, "omnirevolve-image-processor_amd"))
+    import torch.distributed as dist
+    from orip import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = _make(K, seed=2)
+    full[K // 2] = ([], [])                                   # a layer with nothing in it
+    order = list(np.random.default_rng(5).permutation(K))     # the dark -> light order is a permutation of the layers
+    ok = True
+    for g in order:
+        owner = int(g) % world
+        got = P.broadcast_layer(full[g] if owner == rank else None, owner, "cpu")
+        ok &= got[1] == full[g][1] and len(got[0]) == len(full[g][0])
+        ok &= all(np.array_equal(a, b) for a, b in zip(got[0], full[g][0]))
+    dist.barrier(); dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("world,K", [(2, 8), (3, 5)])
+def test_broadcast_layer_stream_gloo(world, K):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_stream, args=(r, world, port, K, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
 @pytest.mark.parametrize("world,K", [(2, 8), (3, 8), (2, 3)])
 def test_exchange_layer_lists_gloo(world, K):
     import torch.multiprocessing as mp
