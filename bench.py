@@ -140,8 +140,19 @@ def main():
                 best = name
         if best:
             e = groups_out[best]
+            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; rocprofv3 cannot run
+            # inside the timed process).  FETCH_SIZE is the raw counter: on gfx950 it shows half the bytes of wide coalesced reads and is
+            # uncalibrated for the byte/dword-granular reads of the walk; WRITE_SIZE is exact.
+            traffic = None; traffic_note = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                if all(k in pm for k in e["kernels"]) and H == 4096 and K == 8 and world == 1:
+                    traffic = int(sum(pm[k]["fetch_bytes_per_launch_raw"] + pm[k]["write_bytes_per_launch"] for k in e["kernels"]))
+                    traffic_note = "profiles/r01_pmc_traffic.json: FETCH_SIZE (raw) + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of this command"
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {"kernel": "+".join(e["kernels"]), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": e["frac"], "traffic": None, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
+                        "frac": e["frac"], "traffic": traffic, "traffic_note": traffic_note, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
 
     # ---- CPU baseline leg (rank 0, N = 1 only): the oracle as a "port", bounded sample
     cpu = None
