@@ -222,18 +222,32 @@ __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sb
 #define ORIP_TAIL_EPS 1e-6
 __global__ __launch_bounds__(256) void k_tail_par(const unsigned* __restrict__ sbase, const unsigned* __restrict__ rank, const double* __restrict__ S, unsigned MS, double T,
                                                    unsigned* __restrict__ npop, unsigned* __restrict__ redo) {
-    unsigned g = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double win[512];
+    const unsigned g0 = blockIdx.x * 256, w0 = g0 >= 256 ? g0 - 256 : 0;      // window = S[w0 .. g0 + 255]
+    for (unsigned t = threadIdx.x; t < 512; t += 256) { const unsigned idx = w0 + t; win[t] = (idx < MS && idx < g0 + 256) ? S[idx] : 0.0; }
+    __syncthreads();
+    unsigned g = g0 + threadIdx.x;
     if (g >= MS) return;
     const unsigned r = rank[g], b = sbase[r];
     const double Sj = S[g];
     bool unsure = !(Sj < 4194304.0) || (g - b) >= (1u << 20);
-    // smallest h in [b, g] with Sj - S[h] <= T; gallop back from g (the tail covers a few dozen samples), then bisect
+    // smallest h in [b, g] with Sj - S[h] <= T.  The tail covers a few dozen samples, so the answer almost always lies in the block's LDS
+    // window (the 256 sums before the block + its own); otherwise gallop back through global memory, then bisect.
     unsigned lo = b, hi = g;                 // answer in [lo, hi]; S[hi] satisfies (Sj - S[g] = 0 <= T)
-    for (unsigned stepb = 1; hi > b; stepb <<= 1) {
-        const unsigned p = (hi - b > stepb) ? hi - stepb : b;
-        if (Sj - S[p] <= T) { hi = p; if (p == b) break; } else { lo = p + 1; break; }
+    const unsigned wlo = max(b, w0);         // first index of my polyline inside the window
+    if (wlo == b || !(Sj - win[wlo - w0] <= T)) {
+        if (wlo > b) lo = wlo + 1; else lo = b;
+        if (wlo > b) { /* S[wlo] fails: answer in (wlo, g] */ }
+        else if (Sj - win[b - w0] <= T) hi = b;                           // the whole prefix fits
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (Sj - win[mid - w0] <= T) hi = mid; else lo = mid + 1; }
+    } else {
+        hi = wlo;                            // S[wlo] still satisfies: continue below the window in global memory
+        for (unsigned stepb = 1; hi > b; stepb <<= 1) {
+            const unsigned p = (hi - b > stepb) ? hi - stepb : b;
+            if (Sj - S[p] <= T) { hi = p; if (p == b) break; } else { lo = p + 1; break; }
+        }
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (Sj - S[mid] <= T) hi = mid; else lo = mid + 1; }
     }
-    while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (Sj - S[mid] <= T) hi = mid; else lo = mid + 1; }
     const unsigned h = lo;
     if (!(Sj - S[h] <= T - ORIP_TAIL_EPS)) unsure = true;
     if (h > b && !(Sj - S[h - 1] > T + ORIP_TAIL_EPS)) unsure = true;
