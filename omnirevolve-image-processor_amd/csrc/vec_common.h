@@ -318,6 +318,8 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // G*G + 1 cell starts
     uint16_t* Eid = reinterpret_cast<uint16_t*>(cst + (G * G + 1));                // entries sorted by cell: idx << 1 | end
     uint8_t* stt = reinterpret_cast<uint8_t*>(Eid + 2 * (size_t)n);                // bit0 used, bit1 closed (rule07)
+    __shared__ uint16_t ring[64];                                                  // (index << 1 | flip) of the last steps: results leave in batches of 64,
+                                                                                   // a store per step would stall the chain on every later s_waitcnt vmcnt
     const int lane = threadIdx.x;
     // ---- load + bounding box
     int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     }
     int cx, cy;
     { short4 e = P[seed]; if (stt[seed] & 2) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; } }
-    if (lane == 0) { order[0] = seed; flips[0] = 0; }
+    if (lane == 0) ring[0] = (uint16_t)(seed << 1);
     __syncthreads();
     int prev = seed;
     unsigned long long d_rounds = 0, d_scanned = 0, d_full = 0;
@@ -412,10 +414,12 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
         float ds = nn_d2(e.x, e.y, cx, cy), de = nn_d2(e.z, e.w, cx, cy);
         const bool cl = (f & 2) != 0;
         const bool flip = cl ? false : !(ds <= de);
-        if (lane == 0) { stt[bi] = f | 1; order[step] = bi; flips[step] = flip ? 1 : 0; }
+        if (lane == 0) { stt[bi] = f | 1; ring[step & 63] = (uint16_t)((bi << 1) | (flip ? 1 : 0)); }
+        if ((step & 63) == 63) { const unsigned v = ring[lane]; order[step - 63 + lane] = (int32_t)(v >> 1); flips[step - 63 + lane] = (uint8_t)(v & 1u); }
         if (cl || flip) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; }
         prev = bi;
     }
+    { const int done = n & ~63; if (done + lane < n) { const unsigned v = ring[lane]; order[done + lane] = (int32_t)(v >> 1); flips[done + lane] = (uint8_t)(v & 1u); } }
     if (dbg && lane == 0) { dbg[0] = d_rounds; dbg[1] = d_scanned; dbg[2] = d_full; dbg[3] = (unsigned long long)cs; }
 }
 // 1 if every coordinate fits int16 (the LDS variant is then exact)

@@ -84,9 +84,10 @@ __global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off,
     info[i] = r;
 }
 __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
-                                                     float* __restrict__ cum, RsInfo* __restrict__ info) {
+                                                     float* __restrict__ cum, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
     const int lane = threadIdx.x;
-    for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
+    for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
+        const int64_t i = ord[rr];                 // longest perimeter first: the long chains start at once, the short ones fill in behind
         RsInfo r = info[i];
         const int64_t n = r.n_eff;
         if (n <= ORIP_LONG_POLY) continue;
@@ -94,16 +95,21 @@ __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ 
         const int64_t nseg = n - 1;
         float acc = 0.f;
         if (lane == 0) s[0] = 0.f;
-        // four windows of 64 segment lengths per turn; the lengths of the next turn are loaded before the serial chain of this one
-        // runs, so the chain never waits for memory
-        auto load4 = [&](int64_t base, float (&sl)[4]) {
+        // four windows of 64 segment lengths per turn.  The POINTS of the next turn are requested before the serial chain of this one
+        // runs and are only turned into lengths after it (using them earlier would make the chain wait for the loads after all).
+        const int2* P2 = reinterpret_cast<const int2*>(p);
+        auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4]) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; sl[w] = (k < nseg) ? vs::seg_len_f32(p, k) : 0.f; }
+            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; const bool in = k < nseg; a[w] = in ? P2[k] : make_int2(0, 0); b2[w] = in ? P2[k + 1] : make_int2(0, 0); }
         };
-        float cur[4], nxt[4];
-        load4(0, cur);
+        auto lengths = [&](const int2 (&a)[4], const int2 (&b2)[4], float (&sl)[4]) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) { float dx = (float)b2[w].x - (float)a[w].x, dy = (float)b2[w].y - (float)a[w].y; float qx = dx * dx, qy = dy * dy; sl[w] = sqrtf(qx + qy); }   // seg_len_f32; padding: 0
+        };
+        int2 ra[4], rb[4]; float cur[4];
+        request(0, ra, rb); lengths(ra, rb, cur);
         for (int64_t base = 0; base < nseg; base += 256) {
-            load4(base + 256, nxt);
+            request(base + 256, ra, rb);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
@@ -116,8 +122,7 @@ __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ 
                 }
                 if (k < nseg) s[k + 1] = pre;
             }
-#pragma unroll
-            for (int w = 0; w < 4; w++) cur[w] = nxt[w];
+            lengths(ra, rb, cur);
         }
         if (lane == 0) { rs_finish(r, acc, n, step); info[i] = r; }
     }
@@ -943,7 +948,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
-        if (kept0.p.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
+        if (kept0.p.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info, ord); }
         tick("cumlen");
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
