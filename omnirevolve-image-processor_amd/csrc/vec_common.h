@@ -106,12 +106,17 @@ __device__ __forceinline__ float pairwise_leaf_g8(const int32_t* __restrict__ xy
     return r;
 }
 #define ORIP_PW_DEPTH 8
+__global__ __launch_bounds__(256) void k_len_keys(const int64_t* __restrict__ off, int64_t n, unsigned* __restrict__ key, unsigned* __restrict__ val) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { int64_t m = off[i + 1] - off[i]; key[i] = (unsigned)(m > 0xffffffffLL ? 0xffffffffLL : m); val[i] = (unsigned)i; }
+}
 __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
-                                                             PolyFeat* __restrict__ out, float* __restrict__ leafbuf) {
+                                                             PolyFeat* __restrict__ out, float* __restrict__ leafbuf, const unsigned* __restrict__ order) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
     __shared__ float part[2 << ORIP_PW_DEPTH];
-    for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
+    for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
+        const int64_t i = order[rr];               // longest first: a block that draws a long polyline late would be the tail of the launch
         PolyFeat f = out[i];
         const int64_t n = f.n;                     // already the open view when requested
         if (n <= ORIP_LONG_POLY) continue;         // uniform for the block
@@ -184,9 +189,14 @@ static int vfeatures(orip_ctx* c, const int64_t* off, const int32_t* pts, int64_
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, off, pts, n, what, feat);
     if (total > ORIP_LONG_POLY) {
-        HIPC(c, LN(c).vtmp[11].ensure(((size_t)(total >> 6) + 2 * (size_t)n + 8) * sizeof(float)));
+        const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
+        HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) + (size_t)n * 16 + 64));
+        float* leafbuf = LN(c).vtmp[11].as<float>();
+        unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
+        hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, off, n, kin, vin);
+        ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
         ProfScope ps(c, "k_poly_features_long");
-        hipLaunchKernelGGL(k_poly_features_long, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, off, pts, n, what, feat, LN(c).vtmp[11].as<float>());
+        hipLaunchKernelGGL(k_poly_features_long, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, off, pts, n, what, feat, leafbuf, vout);
     }
     HIPC(c, hipGetLastError());
     return 0;
