@@ -446,13 +446,22 @@ __global__ __launch_bounds__(256) void k_gather_lens(const GatherDesc* __restric
     if (i < n) lens[i] = d[i].len;
     if (i == n) lens[i] = 0;
 }
+// flat form: a block copies 4096 consecutive OUTPUT points whatever polylines they belong to (one block per polyline would leave
+// the long polylines as the tail of the launch); the polyline of a point is found by bisecting the output offsets once per block
+// and walking forward from there
 __global__ __launch_bounds__(256) void k_gather_pts(const GatherDesc* __restrict__ d, int64_t n, const int32_t* __restrict__ src,
-                                                     const int64_t* __restrict__ out_off, int32_t* __restrict__ dst) {
-    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
-        GatherDesc g = d[k];
-        const int2* s = reinterpret_cast<const int2*>(src) + g.begin;
-        int2* o = reinterpret_cast<int2*>(dst) + out_off[k];
-        for (int64_t j = threadIdx.x; j < g.len; j += 256) o[j] = g.rev ? s[g.len - 1 - j] : s[j];
+                                                     const int64_t* __restrict__ out_off, int32_t* __restrict__ dst, int64_t total) {
+    const int64_t start = (int64_t)blockIdx.x * 4096;
+    if (start >= total) return;
+    int64_t lo = 0, hi = n - 1;                      // last polyline k with out_off[k] <= start
+    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (out_off[mid] <= start) lo = mid; else hi = mid - 1; }
+    int64_t k = lo;
+    const int2* s2 = reinterpret_cast<const int2*>(src); int2* o2 = reinterpret_cast<int2*>(dst);
+    for (int64_t idx = start + threadIdx.x; idx < min(total, start + 4096); idx += 256) {
+        while (out_off[k + 1] <= idx) k++;           // empty polylines are skipped too
+        const GatherDesc g = d[k];
+        const int64_t j = idx - out_off[k];
+        o2[idx] = s2[g.begin + (g.rev ? g.len - 1 - j : j)];
     }
 }
 // Builds dst (DPolys) from descriptors (device array of n descs).  lens/off scratch in ctx->tmpE.
@@ -467,7 +476,7 @@ static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* s
     ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
     dst.total = total;
     HIPC(c, dst.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
-    hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, LN(c).stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>());
+    if (total > 0) hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)cdiv(total, 4096)), dim3(256), 0, LN(c).stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>(), total);
     HIPC(c, hipGetLastError());
     return 0;
 }
