@@ -151,12 +151,13 @@ struct Wave {
         int lx = px - tx0, ly = py - ty0;
         if (!have || (unsigned)(lx - 1) > (unsigned)(WT - 3) || (unsigned)(ly - 1) > (unsigned)(WT - 3)) { load_tile(px, py); lx = px - tx0; ly = py - ty0; }
         li = ly * WTP + lx;
-        u8 v = 0;
-        if (lane < 8) v = tile[li + noff];                            // out-of-image cells of the window hold 0
-        const bool any = (v & ST_FG) && lane != kopp;
-        myv = v;
-        m_any = (unsigned)__ballot(any) & 0xffu;
-        m_unvis = (unsigned)__ballot(any && !(v & ST_VIS)) & 0xffu;
+        unsigned v = 0;
+        if (lane < 8) v = tile[li + noff];                            // out-of-image cells of the window hold 0; lanes >= 8 contribute nothing
+        myv = (u8)v;
+        // two ballots on single-bit tests, the rest on the scalar unit
+        const unsigned m_fg = (unsigned)__ballot((v & ST_FG) != 0), m_vis = (unsigned)__ballot((v & ST_VIS) != 0);
+        m_any = m_fg & ~(1u << kopp);                                  // kopp == 8 clears nothing
+        m_unvis = m_any & ~m_vis;
     }
     __device__ u8 value_of(int k) const { return (u8)__builtin_amdgcn_readlane((int)myv, k); }
     // moves the cursor to neighbour k (after probe); mark: the neighbour becomes visited (it lies inside the window: the cursor is interior)
