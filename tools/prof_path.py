@@ -7,7 +7,7 @@ from orip.device import Device
 from orip import stages as S
 from orip.synth import synth_image, layer_names
 KERNELS = ["k_lab_gather", "k_kmeans_fit", "k_lab_assign", "k_morph_pass", "k_blur_sobel_nms", "k_ccl_init", "k_ccl_merge", "k_ccl_flatten", "k_hyst_mark",
-           "k_hyst_out", "k_thin_sub", "k_skel_state", "k_compact_count", "k_compact_write", "radix_sort_pairs", "k_trace", "k_write_walks", "k_poly_features_long", "k_cumlen_long", "k_scale_pts", "k_greedy_nn", "k_split_small08", "k_poly_features", "k_cumlen", "k_samples", "k_tail_sim", "k_caps_insert",
+           "k_hyst_out", "k_thin_sub", "k_skel_state", "k_compact_count", "k_compact_write", "radix_sort_pairs", "k_trace", "k_write_walks", "k_poly_features_long", "k_cumlen_long", "k_scale_pts", "k_greedy_nn", "k_split_small08", "k_cumlen", "k_samples", "k_tail_sim", "k_caps_insert",
            "k_caps_stamp", "sort_cells", "k_accept", "k_bbox_pairs", "k_stamp_groups", "k_zs_sub", "k_ccl2_merge", "k_comp_paths", "k_cut_slots",
            "k_row_hdist", "k_col_cover", "k_taps_sequential", "k_plot_order"]
 size = int(sys.argv[1]); K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
