@@ -1,0 +1,101 @@
+"""BASELINE.json's full configuration (4096 x 4096, 8 layers) through size-independent properties -- the oracle needs
+~17 minutes for this image, so nothing here calls it:
+
+* schedule independence: the per-layer pipelines (default), one-layer-at-a-time execution and the single-workgroup
+  k-means must all produce byte-identical lines, taps and ops for every layer (checksums of every artefact);
+* stage 04: every contour point is a skeleton pixel of its layer, consecutive points are 8-neighbours, >= 5 points (04:224);
+* stage 05: every scaled point lies inside the margins of the canvas (05:63-96);
+* stage 12: the ops of a layer are a permutation of its lines (each exactly once, possibly flipped) and taps (12:85-187).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H = W = 4096
+K = 8
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from orip.config import Config
+    from orip.device import Device
+    from orip.synth import synth_image, layer_names
+    img = synth_image(H, W, K)
+    cfg = Config(); cfg.color_names = layer_names(K)
+    dev = Device(0)
+    yield dev, cfg, img
+    dev.close()
+
+
+def _digest(dev, cfg):
+    from orip import lib as L, stages as S
+    R = S.r_insert12(cfg)
+    out = {}
+    for g in range(K):
+        h = hashlib.sha256()
+        off, pts = dev.get_polys_flat(L.SLOT_LINES_CROSS, g)
+        h.update(off.tobytes()); h.update(np.ascontiguousarray(pts).tobytes())
+        h.update(np.asarray(dev.get_taps(L.TAPS_CROSS, g), np.int32).tobytes())
+        h.update(np.ascontiguousarray(dev.plot_order(g, R)).tobytes())
+        out[g] = h.hexdigest()
+    return out
+
+
+def test_schedules_and_kernel_variants_agree(setup, monkeypatch):
+    from orip import parallel as P
+    dev, cfg, img = setup
+    digests = []
+    for env in [{}, {"ORIP_SERIAL_LAYERS": "1"}, {"ORIP_KMEANS_1WG": "1", "ORIP_TAIL_SEQ": "1", "ORIP_NN_NOGRID": "1"}]:
+        for k in ("ORIP_SERIAL_LAYERS", "ORIP_KMEANS_1WG", "ORIP_TAIL_SEQ", "ORIP_NN_NOGRID"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev.set_image(img)
+        P.run_path_sharded(dev, cfg, H, W, 0, 1)
+        digests.append(_digest(dev, cfg))
+    assert digests[0] == digests[1] == digests[2]
+
+
+def test_contours_lie_on_the_skeleton_and_scaled_points_on_the_canvas(setup):
+    from orip import lib as L, parallel as P
+    from orip.config import canvas_size_px, margins_px
+    dev, cfg, img = setup
+    dev.set_image(img)
+    P.run_path_sharded(dev, cfg, H, W, 0, 1)
+    sizes = [dev.polys_size(L.SLOT_CONTOURS, l)[1] for l in range(K)]
+    layer = int(np.argmin(sizes))                          # the layer with the fewest contour points (tens of MB on the host)
+    off, pts = dev.get_polys_flat(L.SLOT_CONTOURS, layer)
+    skel = dev.get_skeleton(layer)
+    assert pts[:, 0].min() >= 0 and pts[:, 0].max() < W and pts[:, 1].min() >= 0 and pts[:, 1].max() < H
+    assert skel[pts[:, 1], pts[:, 0]].all()                                  # walks only visit skeleton pixels (04:137-205)
+    lens = np.diff(off)
+    assert lens.min() >= 5                                                   # vectorize_layer keeps paths of >= 5 points (04:224)
+    d = np.abs(np.diff(pts.astype(np.int64), axis=0))
+    inner = np.ones(len(pts) - 1, bool); inner[off[1:-1] - 1] = False        # steps inside a path, not across two paths
+    d_in = d[inner]
+    # a path may end by re-appending its start (04:201-203): that closing step is < 1.5 px too, so every inner step is an 8-neighbour move
+    assert d_in.max() <= 1
+    cw, ch = canvas_size_px(cfg); ml, mr, mt, mb = margins_px(cfg)
+    so, sp = dev.get_polys_flat(L.SLOT_SCALED, layer)
+    assert np.array_equal(so, off)
+    assert sp[:, 0].min() >= ml and sp[:, 0].max() <= cw - mr and sp[:, 1].min() >= mt and sp[:, 1].max() <= ch - mb
+
+
+def test_ops_are_a_permutation_of_lines_and_taps(setup):
+    from orip import lib as L, parallel as P, stages as S
+    dev, cfg, img = setup
+    dev.set_image(img)
+    P.run_path_sharded(dev, cfg, H, W, 0, 1)
+    R = S.r_insert12(cfg)
+    for g in range(K):
+        n_lines = dev.polys_size(L.SLOT_LINES_CROSS, g)[0]
+        taps = dev.get_taps(L.TAPS_CROSS, g)
+        ops = dev.plot_order(g, R)
+        line_ops = ops[ops[:, 0] == 0]; tap_ops = ops[ops[:, 0] == 1]
+        assert sorted(line_ops[:, 1].tolist()) == list(range(n_lines))
+        assert sorted(map(tuple, tap_ops[:, 3:5].tolist())) == sorted(taps)
+        assert np.array_equal(dev.plot_order(g, R), ops)                     # same input, same order
