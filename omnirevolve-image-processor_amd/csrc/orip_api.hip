@@ -4,6 +4,10 @@
 
 thread_local int orip_tls_lane = 0;
 
+void orip_enter(orip_ctx* c) {
+    if (c) hipSetDevice(c->device);      // cheap (thread-local in the runtime); not cached here: the host application may switch devices too
+}
+
 extern "C" int orip_create(int device_id, orip_ctx** out) {
     if (!out) return -1;
     *out = nullptr;
@@ -52,16 +56,21 @@ extern "C" void orip_destroy(orip_ctx* c) {
     delete c;
 }
 
-extern "C" const char* orip_last_error(orip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char* orip_last_error(orip_ctx* c) {
+    orip_enter(c); return c ? c->err.c_str() : "null context"; }
 
 extern "C" int orip_sync(orip_ctx* c) {
+    orip_enter(c);
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 
-extern "C" int orip_prof_enable(orip_ctx* c, int on) { c->prof_on = on != 0; return 0; }
-extern "C" int orip_prof_reset(orip_ctx* c) { c->prof.clear(); return 0; }
+extern "C" int orip_prof_enable(orip_ctx* c, int on) {
+    orip_enter(c); c->prof_on = on != 0; return 0; }
+extern "C" int orip_prof_reset(orip_ctx* c) {
+    orip_enter(c); c->prof.clear(); return 0; }
 extern "C" int orip_prof_get(orip_ctx* c, const char* kernel, double* total_ms, int64_t* launches) {
+    orip_enter(c);
     auto it = c->prof.find(kernel);
     if (it == c->prof.end()) { *total_ms = 0; *launches = 0; return 0; }
     *total_ms = it->second.ms; *launches = it->second.launches;
@@ -69,6 +78,7 @@ extern "C" int orip_prof_get(orip_ctx* c, const char* kernel, double* total_ms, 
 }
 
 extern "C" int orip_set_layer_count(orip_ctx* c, int K) {
+    orip_enter(c);
     if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range", K);
     c->K = K;
     return 0;
@@ -80,11 +90,13 @@ static int check_slot(orip_ctx* c, int slot, int layer) {
 }
 
 extern "C" int orip_polys_size(orip_ctx* c, int slot, int layer, int64_t* n, int64_t* total) {
+    orip_enter(c);
     ORIP_TRY(check_slot(c, slot, layer));
     *n = c->polys[slot][layer].n; *total = c->polys[slot][layer].total;
     return 0;
 }
 extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, int32_t* pts) {
+    orip_enter(c);
     ORIP_TRY(check_slot(c, slot, layer));
     DPolys& P = c->polys[slot][layer];
     if (P.n == 0) { off[0] = 0; return 0; }
@@ -94,6 +106,7 @@ extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, in
     return 0;
 }
 extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const int64_t* off, const int32_t* pts) {
+    orip_enter(c);
     ORIP_TRY(check_slot(c, slot, layer));
     if (n < 0) ORIP_FAIL(c, "negative count");
     DPolys& P = c->polys[slot][layer];
@@ -109,11 +122,13 @@ extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const
     return 0;
 }
 extern "C" int orip_taps_size(orip_ctx* c, int which, int layer, int64_t* n) {
+    orip_enter(c);
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");
     *n = c->taps[which][layer].n;
     return 0;
 }
 extern "C" int orip_get_taps(orip_ctx* c, int which, int layer, int32_t* xy) {
+    orip_enter(c);
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");
     DTaps& T = c->taps[which][layer];
     if (!T.n) return 0;
@@ -122,6 +137,7 @@ extern "C" int orip_get_taps(orip_ctx* c, int which, int layer, int32_t* xy) {
     return 0;
 }
 extern "C" int orip_set_taps(orip_ctx* c, int which, int layer, int64_t n, const int32_t* xy) {
+    orip_enter(c);
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS || n < 0) ORIP_FAIL(c, "bad taps slot");
     DTaps& T = c->taps[which][layer];
     HIPC(c, T.xy.ensure((size_t)std::max<int64_t>(n, 1) * 8 + 64));

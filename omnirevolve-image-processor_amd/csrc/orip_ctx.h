@@ -72,6 +72,10 @@ struct LaneRes {
 };
 extern thread_local int orip_tls_lane;
 #define LN(c) ((c)->ln[orip_tls_lane])
+// HIP's current device is per host thread: every entry point selects the context's GPU for the calling thread (the layer pipelines
+// call in from pool threads, which would otherwise allocate and launch on device 0 of a multi-GPU node)
+struct orip_ctx;
+void orip_enter(orip_ctx* c);
 #define ORIP_LANE_CROSS (ORIP_MAX_LAYERS + 1)
 void orip_contours_free(orip_ctx* c);
 struct LaneGuard { int prev; explicit LaneGuard(int lane) : prev(orip_tls_lane) { orip_tls_lane = lane; } ~LaneGuard() { orip_tls_lane = prev; } };

@@ -680,6 +680,7 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
 // host entry points
 // ------------------------------------------------------------------------------------------------
 extern "C" int orip_set_image(orip_ctx* c, const uint8_t* bgr, int H, int W) {
+    orip_enter(c);
     if (!bgr || H <= 0 || W <= 0) ORIP_FAIL(c, "bad image %dx%d", W, H);
     ORIP_TRY(orip_raster02_lab_tables(c));
     c->H = H; c->W = W;
@@ -689,6 +690,7 @@ extern "C" int orip_set_image(orip_ctx* c, const uint8_t* bgr, int H, int W) {
 }
 
 extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* lab_out) {
+    orip_enter(c);
     if (!c->image.p) ORIP_FAIL(c, "no image set");
     if (!idx) n = (int64_t)c->H * c->W;
     HIPC(c, c->tmpB.ensure((size_t)n * 3 + 16));
@@ -703,6 +705,7 @@ extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* 
 
 extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
                                float* centers_out, double* compactness_out) {
+    orip_enter(c);
     if (!c->image.p) ORIP_FAIL(c, "no image set");
     if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range 1..%d", K, ORIP_MAX_LAYERS);
     int64_t N = sample_idx ? n_idx : (int64_t)c->H * c->W;
@@ -751,6 +754,7 @@ extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n
 
 extern "C" int orip_extract_layers(orip_ctx* c, const float* centers, int K, int open_iters, int close_iters,
                                    float* centers_sorted_out, int64_t* counts_out) {
+    orip_enter(c);
     if (!c->image.p) ORIP_FAIL(c, "no image set");
     if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range", K);
     int H = c->H, W = c->W; int64_t npx = (int64_t)H * W;
@@ -785,12 +789,14 @@ extern "C" int orip_extract_layers(orip_ctx* c, const float* centers, int K, int
 }
 
 extern "C" int orip_get_labels(orip_ctx* c, uint8_t* out) {
+    orip_enter(c);
     if (!c->labels.p) ORIP_FAIL(c, "no labels resident");
     HIPC(c, hipMemcpyAsync(out, c->labels.p, (size_t)c->H * c->W, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
 extern "C" int orip_get_mask(orip_ctx* c, int layer, uint8_t* out) {
+    orip_enter(c);
     if (!c->masks.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no mask for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
     HIPC(c, hipMemcpyAsync(out, c->masks.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));
@@ -798,6 +804,7 @@ extern "C" int orip_get_mask(orip_ctx* c, int layer, uint8_t* out) {
     return 0;
 }
 extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, int W) {
+    orip_enter(c);
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->masks.ensure((size_t)H * W * K));
@@ -806,6 +813,7 @@ extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, i
 }
 
 extern "C" int orip_keep_layers(orip_ctx* c, const int32_t* layers, int n) {
+    orip_enter(c);
     if (!c->masks.p || n < 1 || n > c->K) ORIP_FAIL(c, "bad layer subset (n=%d, K=%d)", n, c->K);
     size_t plane = (size_t)c->H * c->W;
     for (int i = 0; i < n; i++) {

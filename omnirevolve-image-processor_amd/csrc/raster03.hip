@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k_hyst_out(const u8* __restrict__ map, co
 }
 
 extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int close_iters, int gauss_k, int low, int high) {
+    orip_enter(c);
     if (!c->masks.p || c->K < 1) ORIP_FAIL(c, "no masks resident (run orip_extract_layers or orip_set_masks)");
     if (gauss_k != 3 && gauss_k != 5 && gauss_k != 7) ORIP_FAIL(c, "GaussianBlur kernel size %d unsupported (3, 5, 7)", gauss_k);
     int H = c->H, W = c->W, K = c->K; size_t plane = (size_t)H * W;
@@ -217,6 +218,7 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
 }
 
 extern "C" int orip_get_edges(orip_ctx* c, int layer, uint8_t* out) {
+    orip_enter(c);
     if (!c->edges.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no edges for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
     HIPC(c, hipMemcpyAsync(out, c->edges.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));
@@ -224,6 +226,7 @@ extern "C" int orip_get_edges(orip_ctx* c, int layer, uint8_t* out) {
     return 0;
 }
 extern "C" int orip_set_edges(orip_ctx* c, const uint8_t* edges, int K, int H, int W) {
+    orip_enter(c);
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->edges.ensure((size_t)H * W * K));

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void k_kept_slots_base(const unsigned* __restr
 // Everything of stage 04 that is batched over the layers: thinning, components, state bytes, the raster-ordered pixel list
 // sorted by component, the per-layer schedule.  Runs on lane 0 and ends synchronised.
 extern "C" int orip_contours_prepare(orip_ctx* c) {
+    orip_enter(c);
     if (!c->edges.p || c->K < 1) ORIP_FAIL(c, "no edges resident (run orip_detect_edges or orip_set_edges)");
     const int H = c->H, W = c->W, K = c->K;
     if (H > 8192 || W > 8192) ORIP_FAIL(c, "image %dx%d exceeds the 8192x8192 limit of the component key packing", W, H);
@@ -390,6 +391,7 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
 // Contours of one layer (after orip_contours_prepare).  Runs on the layer's own lane, so different layers can be traced from
 // different host threads at the same time and a finished layer can move on to stages 05-08 while others are still walking.
 extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
+    orip_enter(c);
     Prep04* R = static_cast<Prep04*>(c->prep04);
     if (!R || !R->ready) ORIP_FAIL(c, "orip_contours_prepare has not run");
     if (layer < 0 || layer >= c->K) ORIP_FAIL(c, "bad layer %d", layer);
@@ -400,6 +402,7 @@ extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
 }
 
 extern "C" int orip_find_contours(orip_ctx* c) {
+    orip_enter(c);
     ORIP_TRY(orip_contours_prepare(c));
     Prep04& R = *static_cast<Prep04*>(c->prep04);
     if (R.M == 0) return 0;
@@ -410,6 +413,7 @@ extern "C" int orip_find_contours(orip_ctx* c) {
 }
 
 extern "C" int orip_get_skeleton(orip_ctx* c, int layer, uint8_t* out) {
+    orip_enter(c);
     if (!c->skel.p || layer < 0 || layer >= c->K) ORIP_FAIL(c, "no skeleton for layer %d", layer);
     size_t plane = (size_t)c->H * c->W;
     HIPC(c, hipMemcpyAsync(out, c->skel.as<u8>() + plane * layer, plane, hipMemcpyDeviceToHost, LN(c).stream));

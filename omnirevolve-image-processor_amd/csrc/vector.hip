@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, 
 }
 
 extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
+    orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     LaneGuard lane(layer + 1);
     DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
@@ -33,6 +34,7 @@ extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, fl
 }
 
 extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
+    orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     LaneGuard lane(layer + 1);
     ORIP_TRY(vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7));
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(1024) void k_plot_order(const PolyFeat* __restrict_
 }
 
 extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t* n_ops) {
+    orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     LaneGuard lane(layer + 1);
     DPolys& L = c->polys[ORIP_SLOT_LINES_CROSS][layer]; DTaps& T = c->taps[ORIP_TAPS_CROSS][layer];
@@ -176,6 +179,7 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
 }
 
 extern "C" int orip_get_ops(orip_ctx* c, int layer, int32_t* ops5) {
+    orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     if (!c->n_ops[layer]) return 0;
     HIPC(c, hipMemcpyAsync(ops5, c->ops[layer].p, (size_t)c->n_ops[layer] * 20, hipMemcpyDeviceToHost, LN(c).stream));

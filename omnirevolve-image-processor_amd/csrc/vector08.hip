@@ -905,6 +905,7 @@ __global__ __launch_bounds__(256) void k_fill_per(const PolyFeat* __restrict__ f
 }  // namespace
 
 extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm) {
+    orip_enter(c);
     if (!prm || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
     const orip_params08 P = *prm;
     const int W = P.W, H = P.H;

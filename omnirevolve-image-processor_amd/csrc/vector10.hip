@@ -326,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_taps_sequential(const int2* __restrict
 // every orip_dedup_cross_layer call handles the next layer of that order; the calls use their own lane (stream + scratch), so the
 // early layers can be processed while later ones are still in stages 04-08 on their lanes.
 extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
+    orip_enter(c);
     if (!prm) ORIP_FAIL(c, "bad arguments");
     const orip_params10 P = *prm;
     const int W = P.W, H = P.H;
@@ -345,6 +346,7 @@ extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
 // input lists from layer slot `src_layer` (LINES/TAPS_INTRA), output and reporting under `layer`: lets a process that holds its own
 // layers under local indices feed stage 10 in global layer order (multi-GPU layer sharding)
 extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer) {
+    orip_enter(c);
     if (src_layer < 0 || src_layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", src_layer);
     if (!c->p10_ready) ORIP_FAIL(c, "orip_dedup_cross_begin has not run");
     const orip_params10 P = c->p10;
@@ -448,9 +450,11 @@ extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer
     return 0;
 }
 
-extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) { return orip_dedup_cross_layer_from(c, layer, layer); }
+extern "C" int orip_dedup_cross_layer(orip_ctx* c, int layer) {
+    orip_enter(c); return orip_dedup_cross_layer_from(c, layer, layer); }
 
 extern "C" int orip_dedup_cross(orip_ctx* c, const int32_t* order, int n_layers, const orip_params10* prm) {
+    orip_enter(c);
     if (!prm || n_layers < 0 || n_layers > ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
     ORIP_TRY(orip_dedup_cross_begin(c, prm));
     for (int li = 0; li < n_layers; li++) ORIP_TRY(orip_dedup_cross_layer(c, order[li]));
