@@ -324,32 +324,36 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v)
 __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
                                                         int32_t* __restrict__ order, uint8_t* __restrict__ flips, unsigned long long* __restrict__ dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    short4* P = reinterpret_cast<short4*>(smem);                                   // (sx, sy, ex, ey)
+    // end points relative to the bounding-box origin (0 <= v < 2^14: differences, hence all float distances, are unchanged);
+    // bit 15 of .x = used, bit 15 of .y = closed under rule07 (entered at the start only)
+    ushort4* P = reinterpret_cast<ushort4*>(smem);                                 // (sx, sy, ex, ey)
     unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // G*G + 1 cell starts
     uint16_t* Eid = reinterpret_cast<uint16_t*>(cst + (G * G + 1));                // entries sorted by cell: idx << 1 | end
-    uint8_t* stt = reinterpret_cast<uint8_t*>(Eid + 2 * (size_t)n);                // bit0 used, bit1 closed (rule07)
     __shared__ uint16_t ring[64];                                                  // (index << 1 | flip) of the last steps: results leave in batches of 64,
                                                                                    // a store per step would stall the chain on every later s_waitcnt vmcnt
     const int lane = threadIdx.x;
-    // ---- load + bounding box
+    // ---- bounding box
     int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
     for (int i = lane; i < n; i += 64) {
         NNEnds e = ends[i];
-        P[i] = make_short4((short)e.sx, (short)e.sy, (short)e.ex, (short)e.ey);
-        stt[i] = (uint8_t)((i == seed ? 1 : 0) | ((rule07 && e.closed) ? 2 : 0));
         mnx = min(mnx, min(e.sx, e.ex)); mxx = max(mxx, max(e.sx, e.ex)); mny = min(mny, min(e.sy, e.ey)); mxy = max(mxy, max(e.sy, e.ey));
     }
     for (int o = 32; o > 0; o >>= 1) { mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); }
+    const int ox = mnx, oy = mny;
+    for (int i = lane; i < n; i += 64) {
+        NNEnds e = ends[i];
+        P[i] = make_ushort4((unsigned short)((e.sx - ox) | (i == seed ? 0x8000 : 0)), (unsigned short)((e.sy - oy) | ((rule07 && e.closed) ? 0x8000 : 0)),
+                            (unsigned short)(e.ex - ox), (unsigned short)(e.ey - oy));
+    }
     for (int i = lane; i <= G * G; i += 64) cst[i] = 0;
     __syncthreads();
-    const int ox = mnx, oy = mny;
-    int sh = 0; while (((max(mxx - mnx, mxy - mny)) >> sh) >= G) sh++;                // power-of-two cells: (coord - origin) >> sh < G for every end point
+    int sh = 0; while (((max(mxx - mnx, mxy - mny)) >> sh) >= G) sh++;                // power-of-two cells: v >> sh < G for every end point
     const int cs = 1 << sh;
     // ---- counting sort of the entries by cell
     for (int i = lane; i < n; i += 64) {
-        short4 e = P[i];
-        atomicAdd(&cst[((e.y - oy) >> sh) * G + ((e.x - ox) >> sh)], 1u);
-        if (!(stt[i] & 2)) atomicAdd(&cst[((e.w - oy) >> sh) * G + ((e.z - ox) >> sh)], 1u);
+        const ushort4 e = P[i];
+        atomicAdd(&cst[((e.y & 0x7fff) >> sh) * G + ((e.x & 0x7fff) >> sh)], 1u);
+        if (!(e.y & 0x8000)) atomicAdd(&cst[(e.w >> sh) * G + (e.z >> sh)], 1u);
     }
     __syncthreads();
     {   // exclusive scan of the G*G counts: a run of consecutive cells per lane
@@ -364,27 +368,27 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     }
     __syncthreads();
     for (int i = lane; i < n; i += 64) {         // scatter; cst[c] ends up as the END of cell c, i.e. start(c) = c ? cst[c-1] : 0
-        short4 e = P[i];
-        Eid[atomicAdd(&cst[((e.y - oy) >> sh) * G + ((e.x - ox) >> sh)], 1u)] = (uint16_t)(i << 1);
-        if (!(stt[i] & 2)) Eid[atomicAdd(&cst[((e.w - oy) >> sh) * G + ((e.z - ox) >> sh)], 1u)] = (uint16_t)((i << 1) | 1);
+        const ushort4 e = P[i];
+        Eid[atomicAdd(&cst[((e.y & 0x7fff) >> sh) * G + ((e.x & 0x7fff) >> sh)], 1u)] = (uint16_t)(i << 1);
+        if (!(e.y & 0x8000)) Eid[atomicAdd(&cst[(e.w >> sh) * G + (e.z >> sh)], 1u)] = (uint16_t)((i << 1) | 1);
     }
-    int cx, cy;
-    { short4 e = P[seed]; if (stt[seed] & 2) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; } }
+    int cx, cy;                                   // cursor, relative to the origin as well
+    { const ushort4 e = P[seed]; if (e.y & 0x8000) { cx = e.x & 0x7fff; cy = e.y & 0x7fff; } else { cx = e.z; cy = e.w; } }
     if (lane == 0) ring[0] = (uint16_t)(seed << 1);
     __syncthreads();
     int prev = seed;
     unsigned long long d_rounds = 0, d_scanned = 0, d_full = 0;
     for (int step = 1; step < n; step++) {
-        const int gx = (cx - ox) >> sh, gy = (cy - oy) >> sh;
+        const int gx = cx >> sh, gy = cy >> sh;
         unsigned long long best = ~0ULL;
         for (int r = 1;; r = 2 * r + 1) {
             const int x0 = max(0, gx - r), x1 = min(G - 1, gx + r), y0 = max(0, gy - r), y1 = min(G - 1, gy + r);
             unsigned long long mine = ~0ULL;
             auto consider = [&](unsigned q) {
                 const unsigned id = Eid[q]; const int i = (int)(id >> 1);
-                const uint8_t f = stt[i]; const short4 e = P[i];
-                if ((f & 1) || i == prev) return;
-                float v = (id & 1) ? nn_d2(e.z, e.w, cx, cy) : nn_d2(e.x, e.y, cx, cy);
+                const ushort4 e = P[i];
+                if ((e.x & 0x8000) || i == prev) return;
+                float v = (id & 1) ? nn_d2((int)e.z, (int)e.w, cx, cy) : nn_d2((int)(e.x & 0x7fff), (int)(e.y & 0x7fff), cx, cy);
                 unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)i;
                 if (key < mine) mine = key;
             };
@@ -410,33 +414,36 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
             if (dbg) d_rounds++;
             if (x0 == 0 && y0 == 0 && x1 == G - 1 && y1 == G - 1) { if (dbg) d_full++; break; }     // everything scanned
             if (best != ~0ULL) {
-                long long gap = 0x7fffffff;                                          // distance to the nearest unscanned cell, over the open sides
-                if (x0 > 0) gap = min(gap, (long long)(cx - (ox + x0 * cs)) + 1);
-                if (x1 < G - 1) gap = min(gap, (long long)(ox + (x1 + 1) * cs) - cx);
-                if (y0 > 0) gap = min(gap, (long long)(cy - (oy + y0 * cs)) + 1);
-                if (y1 < G - 1) gap = min(gap, (long long)(oy + (y1 + 1) * cs) - cy);
-                double bd = (double)__uint_as_float((unsigned)(best >> 32));
-                if (bd * (1.0 + 1e-6) < (double)gap * (double)gap) break;
+                int gap = 0x7fff;                                                    // distance to the nearest unscanned cell, over the open sides
+                if (x0 > 0) gap = min(gap, cx - (x0 << sh) + 1);
+                if (x1 < G - 1) gap = min(gap, ((x1 + 1) << sh) - cx);
+                if (y0 > 0) gap = min(gap, cy - (y0 << sh) + 1);
+                if (y1 < G - 1) gap = min(gap, ((y1 + 1) << sh) - cy);
+                const float bd = __uint_as_float((unsigned)(best >> 32));
+                if ((double)bd * (1.0 + 1e-6) < (double)(gap * gap)) break;          // gap < 2^15: the square is exact in int
             }
         }
         const int bi = (int)(best & 0xffffffffu);
-        short4 e = P[bi]; const uint8_t f = stt[bi];
-        float ds = nn_d2(e.x, e.y, cx, cy), de = nn_d2(e.z, e.w, cx, cy);
-        const bool cl = (f & 2) != 0;
+        const ushort4 e = P[bi];
+        const int sx = e.x & 0x7fff, sy = e.y & 0x7fff;
+        float ds = nn_d2(sx, sy, cx, cy), de = nn_d2((int)e.z, (int)e.w, cx, cy);
+        const bool cl = (e.y & 0x8000) != 0;
         const bool flip = cl ? false : !(ds <= de);
-        if (lane == 0) { stt[bi] = f | 1; ring[step & 63] = (uint16_t)((bi << 1) | (flip ? 1 : 0)); }
+        if (lane == 0) { reinterpret_cast<unsigned short*>(&P[bi])[0] = (unsigned short)(e.x | 0x8000); ring[step & 63] = (uint16_t)((bi << 1) | (flip ? 1 : 0)); }
         if ((step & 63) == 63) { const unsigned v = ring[lane]; order[step - 63 + lane] = (int32_t)(v >> 1); flips[step - 63 + lane] = (uint8_t)(v & 1u); }
-        if (cl || flip) { cx = e.x; cy = e.y; } else { cx = e.z; cy = e.w; }
+        if (cl || flip) { cx = sx; cy = sy; } else { cx = e.z; cy = e.w; }
         prev = bi;
     }
     { const int done = n & ~63; if (done + lane < n) { const unsigned v = ring[lane]; order[done + lane] = (int32_t)(v >> 1); flips[done + lane] = (uint8_t)(v & 1u); } }
     if (dbg && lane == 0) { dbg[0] = d_rounds; dbg[1] = d_scanned; dbg[2] = d_full; dbg[3] = (unsigned long long)cs; }
 }
-// 1 if every coordinate fits int16 (the LDS variant is then exact)
+// bit 0: some coordinate does not fit int16 (no LDS variant); bit 1: some coordinate outside [-2^14, 2^14) (no grid variant)
 __global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
     int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
     NNEnds q = e[i];
-    if (q.sx < -32768 || q.sx > 32767 || q.sy < -32768 || q.sy > 32767 || q.ex < -32768 || q.ex > 32767 || q.ey < -32768 || q.ey > 32767) *bad = 1;
+    auto out = [&](int lo, int hi) { return q.sx < lo || q.sx > hi || q.sy < lo || q.sy > hi || q.ex < lo || q.ex > hi || q.ey < lo || q.ey > hi; };
+    if (out(-32768, 32767)) atomicOr(bad, 1);
+    if (out(-16384, 16383)) atomicOr(bad, 2);        // the grid variant keeps origin-relative coordinates in 15 bits
 }
 
 // ---- descriptor-driven gather: output polyline k = src points [begin[k], begin[k]+len[k]) (reversed if rev[k]) ----
@@ -541,21 +548,22 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     ORIP_TRY(vread(c, hs, d_seed, 2));
     const int seed = hs[0];
     const size_t lds = (size_t)n * 9 + 16;
-    int G = 64; while (G > 8 && (size_t)G * G > (size_t)n) G >>= 1;          // about one polyline per cell or more
-    size_t lds_grid = (size_t)n * 13 + (size_t)(G * G + 1) * 4 + 32;
-    while (G > 8 && lds_grid > 158 * 1024) { G >>= 1; lds_grid = (size_t)n * 13 + (size_t)(G * G + 1) * 4 + 32; }
+    // grid side: as fine as LDS allows (cells are powers of two, so twice the side is four times fewer candidates per window),
+    // but not many more cells than polylines
+    int G = 8; while (G < 128 && (size_t)(G + 8) * (G + 8) <= 4 * (size_t)n && (size_t)n * 12 + (size_t)((G + 8) * (G + 8) + 1) * 4 + 64 <= 158 * 1024) G += 8;
+    const size_t lds_grid = (size_t)n * 12 + (size_t)(G * G + 1) * 4 + 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_grid), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
-    if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {
+    if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {      // hs[1] == 0: every coordinate in [-2^14, 2^14)
         ProfScope ps(c, "k_greedy_nn");
         unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
         hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips, dbg);
         if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
-    } else if (n <= 16000 && !hs[1]) {
+    } else if (n <= 16000 && !(hs[1] & 1)) {
         ProfScope ps(c, "k_greedy_nn");
         hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, order, flips);
     } else {
