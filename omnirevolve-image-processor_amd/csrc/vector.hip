@@ -154,6 +154,111 @@ __global__ __launch_bounds__(1024) void k_plot_order(const PolyFeat* __restrict_
     (void)found;
 }
 
+// The same greedy as ONE wavefront over LDS-resident end points, taps and alive flags (a layer has a few hundred to a few thousand
+// ops): every choice is a 64-wide scan + DPP minimum with no barrier and no global-memory round trip; the ops leave through a
+// 64-entry ring.  Same keys, same tie-breaks (line k start, line k end, ..., then taps; exact integer d^2).
+__global__ __launch_bounds__(64) void k_plot_order_wave(const PolyFeat* __restrict__ lf, int nl, const int32_t* __restrict__ taps, int nt, double R,
+                                                         int32_t* __restrict__ ops, int* __restrict__ n_ops_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int4* E = reinterpret_cast<int4*>(smem);                       // (sx, sy, ex, ey)
+    int2* T = reinterpret_cast<int2*>(E + nl);
+    uint8_t* aliveL = reinterpret_cast<uint8_t*>(T + nt); uint8_t* aliveT = aliveL + nl;
+    __shared__ int ring[64 * 5];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nl; i += 64) { PolyFeat f = lf[i]; E[i] = make_int4(f.sx, f.sy, f.ex, f.ey); aliveL[i] = 1; }
+    for (int i = lane; i < nt; i += 64) { T[i] = make_int2(taps[2 * i], taps[2 * i + 1]); aliveT[i] = 1; }
+    __syncthreads();
+    long long px = 0, py = 0; int nops = 0;
+    auto emit = [&](int type, int k, int flip, int x, int y) {
+        if (lane == 0) { int* r = ring + 5 * (nops & 63); r[0] = type; r[1] = k; r[2] = flip; r[3] = x; r[4] = y; }
+        nops++;
+        if ((nops & 63) == 0) { const int base = nops - 64; for (int q = lane; q < 320; q += 64) ops[5 * base + q] = ring[q]; }
+    };
+    auto drain = [&]() {          // 12:120-127, 174-181: one forward pass over the alive taps, the cursor follows each drained tap
+        int cursor = 0;
+        while (cursor < nt) {
+            int found = -1;
+            for (int t0 = cursor; t0 < nt && found < 0; t0 += 64) {
+                const int t = t0 + lane; bool ok = false;
+                if (t < nt && aliveT[t]) { const int2 p = T[t]; ok = sqrt((double)d2i(px, py, p.x, p.y)) <= R; }
+                const unsigned long long m = __ballot(ok);
+                if (m) found = t0 + __ffsll((long long)m) - 1;
+            }
+            if (found < 0) break;
+            const int2 p = T[found];
+            if (lane == 0) aliveT[found] = 0;
+            emit(1, -1, 0, p.x, p.y);
+            px = p.x; py = p.y; cursor = found + 1;
+        }
+    };
+    if (nl > 0) {
+        // first = longest line (first maximum), entered from the end nearer to (0,0) (strict <)
+        unsigned long long best = ~0ULL;
+        for (int k = lane; k < nl; k += 64) {
+            unsigned long long key = ((unsigned long long)(~__float_as_uint(lf[k].per)) << 32) | (unsigned)k;   // per >= 0: larger per -> smaller key
+            if (key < best) best = key;
+        }
+        best = wave_min_key(best);
+        const int k = (int)(best & 0xffffffffu);
+        const int4 e = E[k];
+        const int flip = d2i(0, 0, e.z, e.w) < d2i(0, 0, e.x, e.y);
+        if (lane == 0) aliveL[k] = 0;
+        emit(0, k, flip, 0, 0);
+        if (flip) { px = e.x; py = e.y; } else { px = e.z; py = e.w; }
+        drain();
+    } else if (nt > 0) {
+        unsigned long long best = ~0ULL;
+        for (int t = lane; t < nt; t += 64) {
+            const int2 p = T[t];
+            unsigned long long key = ((unsigned long long)d2i(0, 0, p.x, p.y) << 32) | (unsigned)t;
+            if (key < best) best = key;
+        }
+        best = wave_min_key(best);
+        const int t = (int)(best & 0xffffffffu);
+        const int2 p = T[t];
+        if (lane == 0) aliveT[t] = 0;
+        emit(1, -1, 0, p.x, p.y);
+        px = p.x; py = p.y;
+    }
+    const int total = nl + nt;
+    while (nops < total) {
+        unsigned long long best = ~0ULL;
+        for (int k = lane; k < nl; k += 64) {
+            if (!aliveL[k]) continue;
+            const int4 e = E[k];
+            unsigned long long k1 = ((unsigned long long)d2i(px, py, e.x, e.y) << 32) | (unsigned)(2 * k);
+            unsigned long long k2 = ((unsigned long long)d2i(px, py, e.z, e.w) << 32) | (unsigned)(2 * k + 1);
+            if (k1 < best) best = k1;
+            if (k2 < best) best = k2;
+        }
+        for (int t = lane; t < nt; t += 64) {
+            if (!aliveT[t]) continue;
+            const int2 p = T[t];
+            unsigned long long kt = ((unsigned long long)d2i(px, py, p.x, p.y) << 32) | (unsigned)(2 * nl + t);
+            if (kt < best) best = kt;
+        }
+        best = wave_min_key(best);
+        if (best == ~0ULL) break;
+        const unsigned idx = (unsigned)(best & 0xffffffffu);
+        if (idx < (unsigned)(2 * nl)) {
+            const int k = (int)(idx >> 1), flip = (int)(idx & 1u);
+            const int4 e = E[k];
+            if (lane == 0) aliveL[k] = 0;
+            emit(0, k, flip, 0, 0);
+            if (flip) { px = e.x; py = e.y; } else { px = e.z; py = e.w; }
+            drain();
+        } else {
+            const int t = (int)(idx - 2u * (unsigned)nl);
+            const int2 p = T[t];
+            if (lane == 0) aliveT[t] = 0;
+            emit(1, -1, 0, p.x, p.y);
+            px = p.x; py = p.y;
+        }
+    }
+    { const int base = nops & ~63; for (int q = lane; q < 5 * (nops - base); q += 64) ops[5 * base + q] = ring[q]; }
+    if (lane == 0) *n_ops_out = nops;
+}
+
 extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t* n_ops) {
     orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
@@ -170,7 +275,13 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
     HIPC(c, T.xy.ensure(64));
     if (nl) ORIP_TRY(vfeatures(c, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, L.total, 2, feat));
     int* d_n = LN(c).flags.as<int>() + 40;
-    { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
+    const size_t lds = (size_t)nl * 17 + (size_t)nt * 9 + 64;
+    if (lds <= 150 * 1024 && !getenv("ORIP_PLOT_1WG")) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_plot_order_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        ProfScope ps(c, "k_plot_order");
+        hipLaunchKernelGGL(k_plot_order_wave, dim3(1), dim3(64), lds, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, c->ops[layer].as<int32_t>(), d_n);
+    } else { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }
     HIPC(c, hipGetLastError());
     int h = 0;
     ORIP_TRY(vread(c, &h, d_n));
