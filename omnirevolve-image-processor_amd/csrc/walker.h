@@ -62,6 +62,9 @@ struct WalkArgs {
     unsigned long long* dbg;           // optional counters, 8 per component
 };
 
+#ifndef ORIP_WALK_LEAD
+#define ORIP_WALK_LEAD 16       // px by which a reloaded window is shifted in the direction of motion
+#endif
 #ifndef ORIP_WALK_BATCH
 #define ORIP_WALK_BATCH 4u      // first look-up of a no-fresh run after this many pending states; the batch then doubles (at most one state per lane)
 #endif
@@ -86,6 +89,7 @@ struct Wave {
     // the loop only writes LDS: visited marks go to the window at once and to `mlist` (flushed to memory, all lanes, before anything
     // reads the state bytes from memory again); direction codes go to `sbuf` and reach the step log 64 at a time.
     unsigned* mlist; int nm;    // pending marks: (linear index << 4) | state byte
+    int lead_x = 0, lead_y = 0; // window placement ahead of the cursor (ORIP_WALK_LEAD px in the direction of the last step)
     u8* sbuf; unsigned codes_done;
     __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0), px(0), py(0), pl(0), li(0), myv(0), st(nullptr), W(0), H(0) {
         __shared__ u8 lds_tile[WT * WTP];
@@ -123,7 +127,7 @@ struct Wave {
     __device__ void load_tile(int cx, int cy) {
         flush_marks();
         fence();                                                      // earlier marks have reached memory
-        tx0 = ((cx - WT / 2) >> 2) << 2; ty0 = cy - WT / 2;          // 4-byte aligned columns
+        tx0 = ((cx - WT / 2 + lead_x) >> 2) << 2; ty0 = cy - WT / 2 + lead_y;          // 4-byte aligned columns; the window leads in the direction of the last step
         const int y = ty0 + lane;
         u8* row = tile + lane * WTP;
         if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0u; }
@@ -137,7 +141,7 @@ struct Wave {
         have = true; nload++;
         fence();
     }
-    __device__ void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; }
+    __device__ void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; lead_x = lead_y = 0; }
     // marks the cursor pixel itself (start of a walk): global memory and, when inside, the window
     __device__ void mark_cursor(u8 v) {
         if (lane == 0) {
@@ -164,6 +168,7 @@ struct Wave {
     __device__ void step(int k, bool mark) {
         const int dx = (int)((0x9224u >> (2 * k)) & 3u) - 1, dy = (int)((0xA940u >> (2 * k)) & 3u) - 1;
         px += dx; py += dy; pl = (unsigned)((int)pl + dy * W + dx);
+        lead_x = dx * ORIP_WALK_LEAD; lead_y = dy * ORIP_WALK_LEAD;
         if (mark) {
             const u8 v = (u8)(value_of(k) | ST_VIS);
             if (lane == 0) { tile[li + dy * WTP + dx] = v; mlist[nm] = (pl << 4) | v; }
