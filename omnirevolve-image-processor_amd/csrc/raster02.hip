@@ -646,6 +646,72 @@ static unsigned long long make_se_bits(int shape, int k) {
     return se;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Binary fast path of the same chain: a 0/255 mask packs to one bit per pixel (64 pixels per word, 2 MB per 4096^2 layer, so the
+// whole chain of passes runs out of L2), dilation = OR and erosion = AND of shifted rows.  Out-of-image pixels are neutral
+// (erode: ones, dilate: zeros), exactly as in k_morph_pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bits_pack(const u8* __restrict__ src, unsigned long long* __restrict__ bits, int H, int W, int Ww, int labels_mode) {
+    const int layer = blockIdx.z;
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= (size_t)H * Ww) return;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww);
+    const u8* row = (labels_mode ? src : src + (size_t)H * W * layer) + (size_t)y * W;
+    unsigned long long b = 0;
+    const int x0 = xw * 64, n = min(64, W - x0);
+    for (int j = 0; j < n; j++) { const u8 v = row[x0 + j]; if (labels_mode ? (v == layer) : (v != 0)) b |= 1ULL << j; }
+    bits[(size_t)H * Ww * layer + wi] = b;
+}
+__global__ __launch_bounds__(256) void k_bits_unpack(const unsigned long long* __restrict__ bits, u8* __restrict__ dst, int H, int W, int Ww) {
+    const int layer = blockIdx.z;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;                // four pixels per thread
+    const size_t plane = (size_t)H * W;
+    if (p * 4 >= plane) return;
+    u8* d = dst + plane * layer;
+    for (int j = 0; j < 4; j++) {
+        const size_t q = p * 4 + j; if (q >= plane) break;
+        const int y = (int)(q / W), x = (int)(q % W);
+        d[q] = ((bits[((size_t)layer * H + y) * Ww + (x >> 6)] >> (x & 63)) & 1ULL) ? 255 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_morph_bits(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int H, int W, int Ww, int k,
+                                                     unsigned long long se, int dilate) {
+    const int layer = blockIdx.z;
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= (size_t)H * Ww) return;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww), r = k >> 1;
+    const unsigned long long* s = src + (size_t)H * Ww * layer;
+    const unsigned long long neutral = dilate ? 0ULL : ~0ULL;
+    const int tail = W - (Ww - 1) * 64;                                       // valid bits of the last word of a row
+    const unsigned long long tail_mask = tail >= 64 ? ~0ULL : ((1ULL << tail) - 1ULL);
+    auto word = [&](int yy, int xx) -> unsigned long long {                   // row yy, word xx with out-of-image bits made neutral
+        if (yy < 0 || yy >= H || xx < 0 || xx >= Ww) return neutral;
+        unsigned long long w = s[(size_t)yy * Ww + xx];
+        if (xx == Ww - 1) w = dilate ? (w & tail_mask) : (w | ~tail_mask);
+        return w;
+    };
+    unsigned long long out = neutral;
+    for (int a = 0; a < k; a++) {
+        if (!((se >> (a * k)) & ((1ULL << k) - 1ULL))) continue;
+        const int yy = y + a - r;
+        const unsigned long long L = word(yy, xw - 1), M = word(yy, xw), Rw = word(yy, xw + 1);
+        for (int b = 0; b < k; b++) {
+            if (!((se >> (a * k + b)) & 1ULL)) continue;
+            const int sft = b - r;                                             // output bit x takes source bit x + sft
+            unsigned long long v = sft == 0 ? M : (sft > 0 ? ((M >> sft) | (Rw << (64 - sft))) : ((M << -sft) | (L >> (64 + sft))));
+            out = dilate ? (out | v) : (out & v);
+        }
+    }
+    dst[(size_t)H * Ww * layer + wi] = out;
+}
+// 1 if any byte of the planes is neither 0 nor 255
+__global__ __launch_bounds__(256) void k_not_binary(const u8* __restrict__ src, size_t n, int* __restrict__ flag) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    bool bad = false;
+    for (int j = 0; j < 16 && i + j < n; j++) { const u8 v = src[i + j]; bad |= (v != 0 && v != 255); }
+    if (bad) *flag = 1;
+}
+
 // open (erode^n, dilate^n) then close (dilate^n, erode^n); src plane(s) -> dst plane(s); uses tmpA as ping-pong
 int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode) {
     if (k < 1 || k > 7 || (k & 1) == 0) ORIP_FAIL(c, "structuring element size %d unsupported (odd, 1..7)", k);
@@ -657,6 +723,30 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
     for (int i = 0; i < std::max(close_iters, 0); i++) passes.push_back(1);
     for (int i = 0; i < std::max(close_iters, 0); i++) passes.push_back(0);
     if (passes.empty()) passes.push_back(-1);   // identity copy via 1x1 "erode"
+    // binary input (label masks always are; explicit masks are checked): the chain runs on bit planes
+    bool binary = labels_mode;
+    if (!binary && !getenv("ORIP_MORPH_BYTES")) {
+        int* d_flag = LN(c).flags.as<int>() + 12;
+        HIPC(c, hipMemsetAsync(d_flag, 0, 4, LN(c).stream));
+        hipLaunchKernelGGL(k_not_binary, dim3((unsigned)cdiv((int64_t)(plane * K), 4096)), dim3(256), 0, LN(c).stream, src, plane * K, d_flag);
+        int h = 1; HIPC(c, hipMemcpyAsync(&h, d_flag, 4, hipMemcpyDeviceToHost, LN(c).stream)); HIPC(c, hipStreamSynchronize(LN(c).stream));
+        binary = h == 0;
+    }
+    if (binary && passes[0] >= 0 && !getenv("ORIP_MORPH_BYTES")) {
+        const int Ww = (W + 63) >> 6; const size_t nw = (size_t)H * Ww;
+        HIPC(c, c->tmpA.ensure(std::max(plane * K, nw * K * 16 + 64)));
+        unsigned long long* A = c->tmpA.as<unsigned long long>(); unsigned long long* B = A + nw * K;
+        dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K), block(256);
+        hipLaunchKernelGGL(k_bits_pack, gw, block, 0, LN(c).stream, src, A, H, W, Ww, labels_mode ? 1 : 0);
+        for (size_t i = 0; i < passes.size(); i++) {
+            ProfScope ps(c, "k_morph_pass");
+            hipLaunchKernelGGL(k_morph_bits, gw, block, 0, LN(c).stream, A, B, H, W, Ww, k, se, passes[i] == 1 ? 1 : 0);
+            std::swap(A, B);
+        }
+        hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     HIPC(c, c->tmpA.ensure(plane * K));
     dim3 grid(cdiv(W, MT_X), cdiv(H, MT_Y), K), block(256);
     const u8* cur = src; bool lm = labels_mode;
