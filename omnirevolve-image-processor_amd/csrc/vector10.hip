@@ -322,6 +322,41 @@ __global__ __launch_bounds__(1024) void k_taps_sequential(const int2* __restrict
     if (threadIdx.x == 0) *n_acc_out = nacc;
 }
 
+// the same sequential filter by one wavefront: the raster test of every candidate is order-free (the raster only changes after the
+// loop) and is done up front; the candidates and the accepted list then live in LDS and each candidate is checked against the
+// accepted ones 64 at a time
+__global__ __launch_bounds__(64) void k_taps_wave(const int2* __restrict__ seq, int n, int r, const u8* __restrict__ forb, int H, int W,
+                                                   int2* __restrict__ acc_out, int* __restrict__ n_acc_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int2* cand = reinterpret_cast<int2*>(smem); int2* acc = cand + n;
+    uint8_t* st = reinterpret_cast<uint8_t*>(acc + n);            // 0: rejected by the raster, 1: inside, 2: outside the canvas (accepted as is)
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) {
+        const int2 p = seq[i]; cand[i] = p;
+        const bool inside = (p.y >= 0 && p.y < H && p.x >= 0 && p.x < W);
+        st[i] = inside ? (forb[(size_t)p.y * W + p.x] != 0 ? 0 : 1) : 2;
+    }
+    __syncthreads();
+    const long long r2 = (long long)r * r;
+    int nacc = 0;
+    for (int i = 0; i < n; i++) {
+        const uint8_t s = st[i];
+        if (s == 0) continue;
+        const int2 p = cand[i];
+        bool hit = false;
+        if (s == 1) {
+            for (int j0 = 0; j0 < nacc && !hit; j0 += 64) {
+                const int j = j0 + lane; bool h = false;
+                if (j < nacc) { const int2 a = acc[j]; const long long dx = a.x - p.x, dy = a.y - p.y; h = dx * dx + dy * dy <= r2; }
+                hit = __ballot(h) != 0;
+            }
+        }
+        if (!hit) { if (lane == 0) acc[nacc] = p; nacc++; }
+    }
+    for (int i = lane; i < nacc; i += 64) acc_out[i] = acc[i];
+    if (lane == 0) *n_acc_out = nacc;
+}
+
 // Stage 10 keeps one cumulative "forbidden" raster while it walks the layers from dark to light (10:166-212).  begin clears it,
 // every orip_dedup_cross_layer call handles the next layer of that order; the calls use their own lane (stream + scratch), so the
 // early layers can be processed while later ones are still in stages 04-08 on their lanes.
@@ -434,7 +469,13 @@ extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer
         HIPC(c, Tout.xy.ensure((size_t)std::max<int64_t>(n_seq, 1) * 8 + 64));
         if (n_seq > 0) {
             int* d_n = LN(c).flags.as<int>() + 44;
-            { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
+            const size_t lds_t = (size_t)n_seq * 17 + 64;
+            if (lds_t <= 150 * 1024 && !getenv("ORIP_TAPS_1WG")) {
+                static bool attr_set = false;
+                if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_taps_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+                ProfScope ps(c, "k_taps_sequential");
+                hipLaunchKernelGGL(k_taps_wave, dim3(1), dim3(64), lds_t, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n);
+            } else { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
             int na = 0;
             ORIP_TRY(vread(c, &na, d_n));
             Tout.n = na;
