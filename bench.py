@@ -38,7 +38,9 @@ def kernel_groups(H, W, K, n_points):
     px = H * W
     return {
         "lab_assign": (["k_lab_assign"], 4 * px, "launch", "3 B BGR in + 1 B label out per pixel"),
-        "morph_pass": (["k_morph_pass"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and pass"),
+        "morph_pass": (["k_morph_pass"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and pass (byte kernel: non-binary masks only)"),
+        "morph_bits": (["k_morph_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and pass; the bit planes (2 MB per layer) stay in L2, "
+                       "so this is cache traffic, not HBM traffic"),
         "blur_sobel_nms": (["k_blur_sobel_nms"], 2 * K * px, "launch", "1 B mask in + 1 B NMS map out per pixel per layer"),
         "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration"),
         "ccl_merge": (["k_ccl_merge"], 5 * K * px, "launch", "1 B image + 4 B parent per pixel per layer"),

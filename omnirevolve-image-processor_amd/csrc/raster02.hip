@@ -739,7 +739,7 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K), block(256);
         hipLaunchKernelGGL(k_bits_pack, gw, block, 0, LN(c).stream, src, A, H, W, Ww, labels_mode ? 1 : 0);
         for (size_t i = 0; i < passes.size(); i++) {
-            ProfScope ps(c, "k_morph_pass");
+            ProfScope ps(c, "k_morph_bits");
             hipLaunchKernelGGL(k_morph_bits, gw, block, 0, LN(c).stream, A, B, H, W, Ww, k, se, passes[i] == 1 ? 1 : 0);
             std::swap(A, B);
         }
