@@ -96,8 +96,9 @@ def test_stage02_labels_and_masks(dev, case):
 
 
 @pytest.mark.parametrize("prm", [dict(), dict(edge_kernel_size=5, edge_low_threshold=22, edge_high_threshold=70),
-                                 dict(edge_kernel_size=7, edge_morph_kernel=5), dict(edge_morph_open_iters=2, edge_morph_close_iters=0)])
-@pytest.mark.parametrize("shape", [(130, 170), (256, 256)])
+                                 dict(edge_kernel_size=7, edge_morph_kernel=5), dict(edge_morph_open_iters=2, edge_morph_close_iters=0),
+                                 dict(edge_morph_kernel=7, edge_morph_open_iters=1, edge_morph_close_iters=2)])
+@pytest.mark.parametrize("shape", [(130, 170), (256, 256), (50, 40)])
 def test_stage03_edges(dev, prm, shape):
     rng = np.random.default_rng(4)
     H, W = shape
