@@ -1160,8 +1160,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 hipLaunchKernelGGL(k_comp_classes, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, NC, cs, cap0, cap1, std::max(2, P.post_minlen), counts, l0, l1, l2, outcnt);
                 CompArgs A; A.corder = corder; A.cs = cs; A.lin = lin; A.gid = gid; A.g = grp; A.cid = cid; A.nbr = nbr; A.Wp = Wp; A.min_len = P.post_minlen; A.step = stp;
                 A.eps = (float)P.post_eps; A.outpts = outpts; A.outcnt = outcnt;
-                static bool attr_set = false;
-                if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_paths_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); attr_set = true; }
+                static std::once_flag attr_once;            // several layer threads may arrive here together
+                std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_paths_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); });
                 ProfScope ps(c, "k_comp_paths");
                 hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 8192u)), dim3(64), lds_bytes(cap0), LN(c).stream, A, l0, counts + 0, cap0, pcap_of(cap0));
                 hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 1024u)), dim3(64), lds_bytes(cap1), LN(c).stream, A, l1, counts + 1, cap1, pcap_of(cap1));

@@ -471,8 +471,8 @@ extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer
             int* d_n = LN(c).flags.as<int>() + 44;
             const size_t lds_t = (size_t)n_seq * 17 + 64;
             if (lds_t <= 150 * 1024 && !getenv("ORIP_TAPS_1WG")) {
-                static bool attr_set = false;
-                if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_taps_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+                static std::once_flag attr_once;            // several layer threads may arrive here together
+                std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_taps_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
                 ProfScope ps(c, "k_taps_sequential");
                 hipLaunchKernelGGL(k_taps_wave, dim3(1), dim3(64), lds_t, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n);
             } else { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
