@@ -503,6 +503,69 @@ __global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __
         d[o] = v ? 255 : 0;
     }
 }
+// ---- the same thinning on bit planes (one bit per pixel, 64 pixels per word; the padded canvas is 12.8 MB, i.e. cache-resident).
+// A sub-iteration evaluates the Zhang-Suen conditions for 64 pixels at once with bit-sliced logic: the eight neighbour planes come
+// from the three rows by word shifts, B = P2+...+P9 from a carry-save adder tree, A == 1 ("exactly one 0->1 transition") from a
+// one/two accumulator.  Same conditions as k_zs_sub (08:349-366), out-of-image pixels are background.
+__global__ __launch_bounds__(256) void k_gid_to_bits(const unsigned* __restrict__ gid, unsigned long long* __restrict__ bits, int H, int W, int Ww) {
+    // a wave packs 64 consecutive words: one coalesced 256-byte read + one ballot per word, then one coalesced write of the 64 words
+    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, nw = (size_t)H * Ww;
+    if (w0 >= nw) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long mine = 0;
+    for (int j = 0; j < 64; j++) {
+        const size_t wi = w0 + j;
+        bool fg = false;
+        if (wi < nw) { const int y = (int)(wi / Ww), x = (int)(wi % Ww) * 64 + lane; fg = x < W && gid[(size_t)y * W + x] != 0; }
+        const unsigned long long b = __ballot(fg);
+        if (lane == j) mine = b;
+    }
+    if (w0 + lane < nw) bits[w0 + lane] = mine;
+}
+__global__ __launch_bounds__(256) void k_bits_to_mask(const unsigned long long* __restrict__ bits, u8* __restrict__ m, int H, int W, int Ww) {
+    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, nw = (size_t)H * Ww;
+    if (w0 >= nw) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mine = (w0 + lane < nw) ? bits[w0 + lane] : 0ULL;
+    for (int j = 0; j < 64; j++) {
+        const size_t wi = w0 + j; if (wi >= nw) break;
+        const unsigned long long b = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+        const int y = (int)(wi / Ww), x = (int)(wi % Ww) * 64 + lane;
+        if (x < W) m[(size_t)y * W + x] = ((b >> lane) & 1ULL) ? 255 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __restrict__ s, unsigned long long* __restrict__ d, int H, int Ww, int sub, int* __restrict__ changed) {
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= (size_t)H * Ww) return;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww);
+    const unsigned long long M = s[wi];
+    if (!M) { d[wi] = 0; return; }
+    auto W64 = [&](int yy, int xx) -> unsigned long long { return (yy < 0 || yy >= H || xx < 0 || xx >= Ww) ? 0ULL : s[(size_t)yy * Ww + xx]; };
+    const unsigned long long U = W64(y - 1, xw), UL = W64(y - 1, xw - 1), UR = W64(y - 1, xw + 1);
+    const unsigned long long ML = W64(y, xw - 1), MR = W64(y, xw + 1);
+    const unsigned long long D = W64(y + 1, xw), DL = W64(y + 1, xw - 1), DR = W64(y + 1, xw + 1);
+    // neighbour planes in the reference's numbering: P2 = north, then clockwise
+    const unsigned long long P2 = U, P3 = (U >> 1) | (UR << 63), P4 = (M >> 1) | (MR << 63), P5 = (D >> 1) | (DR << 63);
+    const unsigned long long P6 = D, P7 = (D << 1) | (DL >> 63), P8 = (M << 1) | (ML >> 63), P9 = (U << 1) | (UL >> 63);
+    // B = number of foreground neighbours, bit-sliced (b0 ones, b1 twos, b2 fours, b3 eights)
+    auto FA = [](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long& sum, unsigned long long& carry) { const unsigned long long t = a ^ b; sum = t ^ c; carry = (a & b) | (t & c); };
+    unsigned long long s1, c1, s2, c2, s4, c4, s5, c5;
+    FA(P2, P3, P4, s1, c1); FA(P5, P6, P7, s2, c2);
+    const unsigned long long s3 = P8 ^ P9, c3 = P8 & P9;
+    FA(s1, s2, s3, s4, c4);
+    FA(c1, c2, c3, s5, c5);
+    const unsigned long long b0 = s4, b1 = s5 ^ c4, c6 = s5 & c4, b2 = c5 ^ c6, b3 = c5 & c6;
+    const unsigned long long Bok = (b1 | b2) & ~b3 & ~(b2 & b1 & b0);          // 2 <= B <= 6
+    // A = number of 0 -> 1 transitions in P2, P3, ..., P9, P2: exactly one
+    unsigned long long one = 0, two = 0;
+    auto TR = [&](unsigned long long a, unsigned long long b) { const unsigned long long t = ~a & b; two |= one & t; one |= t; };
+    TR(P2, P3); TR(P3, P4); TR(P4, P5); TR(P5, P6); TR(P6, P7); TR(P7, P8); TR(P8, P9); TR(P9, P2);
+    const unsigned long long Aok = one & ~two;
+    const unsigned long long cnd = sub == 0 ? (~(P2 & P4 & P6) & ~(P4 & P6 & P8)) : (~(P2 & P4 & P8) & ~(P2 & P6 & P8));
+    const unsigned long long del = M & Aok & Bok & cnd;
+    if (del) *changed = 1;
+    d[wi] = M & ~del;
+}
 // plain (linear id) union-find CCL on the padded raster
 __global__ __launch_bounds__(256) void k_ccl2_init(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1077,9 +1140,24 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         { ProfScope ps(c, "k_stamp_groups"); hipLaunchKernelGGL(k_stamp_groups, dim3(8192), dim3(256), 0, LN(c).stream, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, par, rad, gid, Wp, Hp); }
         dim3 g2(cdiv(Wp, 64), cdiv(Hp, 4)), blk(256);
         const size_t ntile_max = (size_t)g2.x * g2.y;
-        HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + ntile_max * 4 + 128));
+        const int Wwp = (Wp + 63) >> 6; const size_t nwords = (size_t)Hp * Wwp;
+        HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + ntile_max * 4 + nwords * 16 + 256));
         u8* skA = LN(c).vtmp[9].as<u8>(); u8* skB = skA + Np; unsigned* tiles = (unsigned*)(skB + ((Np + 15) & ~(size_t)15));
+        unsigned long long* bA = (unsigned long long*)(tiles + ((ntile_max + 3) & ~(size_t)3)); unsigned long long* bB = bA + nwords;
         int* d_changed = LN(c).flags.as<int>() + 48; unsigned* d_ntiles = LN(c).flags.as<unsigned>() + 52;
+        if (!getenv("ORIP_THIN_BYTES")) {
+            const dim3 gwd((unsigned)cdiv((int64_t)nwords, 256));
+            hipLaunchKernelGGL(k_gid_to_bits, gwd, blk, 0, LN(c).stream, gid, bA, Hp, Wp, Wwp);      // 4 waves x 64 words per block
+            tick("raster");
+            for (int it = 0; it < 48; it++) {
+                HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
+                { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_changed); }
+                { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_changed); }
+                int ch = 0; ORIP_TRY(vread(c, &ch, d_changed));
+                if (!ch) break;
+            }
+            hipLaunchKernelGGL(k_bits_to_mask, gwd, blk, 0, LN(c).stream, bA, skA, Hp, Wp, Wwp);
+        } else {
         HIPC(c, hipMemsetAsync(d_ntiles, 0, 4, LN(c).stream));
         HIPC(c, hipMemsetAsync(skB, 0, Np, LN(c).stream));
         hipLaunchKernelGGL(k_gid_to_mask, g2, blk, 0, LN(c).stream, gid, skA, Hp, Wp, tiles, d_ntiles);
@@ -1091,6 +1169,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_sub, gz, blk, 0, LN(c).stream, skB, skA, Hp, Wp, 1, d_changed, tiles, d_ntiles, (int)g2.x); }
             int ch = 0; ORIP_TRY(vread(c, &ch, d_changed));
             if (!ch) break;
+        }
         }
         tick("thin");
         // components
