@@ -1242,9 +1242,14 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 static std::once_flag attr_once;            // several layer threads may arrive here together
                 std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_paths_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); });
                 ProfScope ps(c, "k_comp_paths");
+                // the few large components are long serial chains: they start on the side stream while the many small ones run here
+                HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));
+                HIPC(c, hipStreamWaitEvent(LN(c).stream2, LN(c).ev2, 0));
+                hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 1024u)), dim3(64), lds_bytes(cap1), LN(c).stream2, A, l1, counts + 1, cap1, pcap_of(cap1));
+                hipLaunchKernelGGL(k_comp_paths_glb, dim3(std::min(NC, 1024u)), dim3(64), 0, LN(c).stream2, A, l2, counts + 2, X);
+                HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream2));
                 hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 8192u)), dim3(64), lds_bytes(cap0), LN(c).stream, A, l0, counts + 0, cap0, pcap_of(cap0));
-                hipLaunchKernelGGL(k_comp_paths_lds, dim3(std::min(NC, 1024u)), dim3(64), lds_bytes(cap1), LN(c).stream, A, l1, counts + 1, cap1, pcap_of(cap1));
-                hipLaunchKernelGGL(k_comp_paths_glb, dim3(std::min(NC, 1024u)), dim3(64), 0, LN(c).stream, A, l2, counts + 2, X);
+                HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));
                 tick("paths");
                 hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, LN(c).stream, outcnt, NC, oflag);
                 ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
