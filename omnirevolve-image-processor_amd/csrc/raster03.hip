@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ img, in
     const u8* s = img + plane * blockIdx.z; int* L = par + pplane * blockIdx.z;
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    int id = px_id(y, x, Wb);
-    L[id] = (s[(size_t)y * W + x] != bg_value) ? id : -1;
+    // only foreground entries are ever read (union-find chains stay inside the foreground, every consumer tests the pixel first),
+    // so the 4-byte parents of the background -- 98 % of the plane -- are not written at all
+    if (s[(size_t)y * W + x] != bg_value) { const int id = px_id(y, x, Wb); L[id] = id; }
 }
 __global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ img, int* __restrict__ par, int H, int W, int bg_value) {
     const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
@@ -150,22 +151,22 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ img, i
     }
 }
 // plane-aware flatten
-__global__ __launch_bounds__(256) void k_ccl_flatten2(int* __restrict__ par, int pplane) {
-    int* L = par + (size_t)pplane * blockIdx.z;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pplane) return;
-    if (L[i] < 0) return;
-    L[i] = uf_find(L, i);
+__global__ __launch_bounds__(256) void k_ccl_flatten2(const u8* __restrict__ img, int* __restrict__ par, int H, int W, int bg_value) {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    const size_t plane = (size_t)H * W, pplane = (size_t)Wb * Hb * 4;
+    const u8* s = img + plane * blockIdx.z; int* L = par + pplane * blockIdx.z;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    if (s[(size_t)y * W + x] == bg_value) return;
+    const int id = px_id(y, x, Wb);
+    L[id] = uf_find(L, id);
 }
-
 int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value) {
     int H = c->H, W = c->W;
-    int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1, pplane = Wb * Hb * 4;
     dim3 grid(cdiv(W, 64), cdiv(H, 4), K), block(256);
-    if ((W & 1) || (H & 1)) HIPC(c, hipMemsetAsync(par, 0xff, (size_t)pplane * K * sizeof(int), LN(c).stream));  // ids of absent pixels
     { ProfScope ps(c, "k_ccl_init"); hipLaunchKernelGGL(k_ccl_init, grid, block, 0, LN(c).stream, img, par, H, W, bg_value); }
     { ProfScope ps(c, "k_ccl_merge"); hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, LN(c).stream, img, par, H, W, bg_value); }
-    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_flatten2, dim3(cdiv(pplane, 256), 1, K), block, 0, LN(c).stream, par, pplane); }
+    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_flatten2, grid, block, 0, LN(c).stream, img, par, H, W, bg_value); }
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __res
 __global__ __launch_bounds__(256) void k_ccl2_init(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    int id = y * W + x; L[id] = s[id] ? id : -1;
+    int id = y * W + x; if (s[id]) L[id] = id;          // background parents are never read: not written either
 }
 __global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, in
         if (x + 1 < W && s[id - W + 1]) uunite(L, id, id - W + 1);
     }
 }
-__global__ __launch_bounds__(256) void k_ccl2_flatten(int* __restrict__ L, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n && L[i] >= 0) L[i] = ufind(L, i); }
+__global__ __launch_bounds__(256) void k_ccl2_flatten(const u8* __restrict__ s, int* __restrict__ L, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n && s[i]) L[i] = ufind(L, i); }
 // ordered compaction of skeleton pixels (count / write), 1024 px per block
 __global__ __launch_bounds__(256) void k_sk_count(const u8* __restrict__ s, int64_t n, unsigned* __restrict__ counts) {
     __shared__ unsigned ws[4];
@@ -1177,7 +1177,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         int* L2 = LN(c).vtmp[10].as<int>();
         hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp);
         { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp); }
-        hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, L2, (int)Np);
+        hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, skA, L2, (int)Np);
         tick("c:ccl");
         const int nblk = cdiv((int64_t)Np, 1024);
         HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
