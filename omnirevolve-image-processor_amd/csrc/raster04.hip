@@ -165,6 +165,7 @@ struct Prep04 {
     WalkArgs A;                                     // shared arguments (state bytes, keys, lin, comp_start, memo, winfo, total_fg)
     unsigned F[ORIP_MAX_LAYERS];                    // log capacity factor of the trace in flight
     bool launched[ORIP_MAX_LAYERS];
+    bool memo_clear[ORIP_MAX_LAYERS];               // the layer's memo plane was zeroed on its lane while the raster part ran
 };
 void orip_contours_free(orip_ctx* c) { delete static_cast<Prep04*>(c->prep04); c->prep04 = nullptr; }
 
@@ -191,8 +192,16 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     if (!c->prep04) c->prep04 = new Prep04();
     Prep04& R = *static_cast<Prep04*>(c->prep04);
     R.ready = false;
-    for (int l = 0; l < ORIP_MAX_LAYERS; l++) { R.launched[l] = false; R.F[l] = 0; }
+    for (int l = 0; l < ORIP_MAX_LAYERS; l++) { R.launched[l] = false; R.F[l] = 0; R.memo_clear[l] = false; }
     const size_t plane = (size_t)H * W; const int64_t n = (int64_t)plane * K;
+    // the memo planes (one word per pixel and incoming direction, 0.5 GB per layer at 4096^2) are cleared on the layer lanes now,
+    // underneath the raster work below, instead of in front of every layer's trace
+    HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
+    for (int l = 0; l < K; l++) {
+        LaneGuard lane(l + 1);
+        HIPC(c, hipMemsetAsync(c->ln[0].vtmp[6].as<unsigned>() + plane * 8 * l, 0, plane * 8 * 4, LN(c).stream));
+        R.memo_clear[l] = true;
+    }
     // ---- thinning_zhangsuen (04:35-99): <=120 iterations of two sub-iterations, until nothing is deleted
     HIPC(c, c->skel.ensure(plane * K + 16));
     HIPC(c, c->tmpB.ensure(plane * K + 16));
@@ -314,7 +323,8 @@ static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F) {
     A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)F * b0 + (size_t)256 * c0);
     A.cap_factor = F; A.comp_order = R.order + c0; A.nc = NCl;
     int* d_over = LN(c).flags.as<int>() + 20; A.overflow = d_over;
-    HIPC(c, hipMemsetAsync(A.memo + plane * 8 * layer, 0, plane * 8 * 4, LN(c).stream));
+    if (!R.memo_clear[layer]) HIPC(c, hipMemsetAsync(A.memo + plane * 8 * layer, 0, plane * 8 * 4, LN(c).stream));
+    R.memo_clear[layer] = false;                     // a retry (or a second trace without prepare) clears it itself
     HIPC(c, hipMemsetAsync(A.winfo + 2 * (size_t)b0, 0, (size_t)2 * Ml * sizeof(WalkInfo), LN(c).stream));
     HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
     if (getenv("ORIP_WALK_DBG")) {          // per-component counters (walks, steps, memo hits, closed cycles, tile loads, size)
