@@ -42,7 +42,8 @@ def kernel_groups(H, W, K, n_points):
         "morph_bits": (["k_morph_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and pass; the bit planes (2 MB per layer) stay in L2, "
                        "so this is cache traffic, not HBM traffic"),
         "blur_sobel_nms": (["k_blur_sobel_nms"], 2 * K * px, "launch", "1 B mask in + 1 B NMS map out per pixel per layer"),
-        "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration"),
+        "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration (byte kernel, ORIP_THIN_BYTES only)"),
+        "thin_bits": (["k_thin_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and sub-iteration; bit planes of 2 MB per layer: cache traffic"),
         "ccl_merge": (["k_ccl_merge"], 5 * K * px, "launch", "1 B image + 4 B parent per pixel per layer"),
         "stage04_write": (["k_write_walks"], 8 * n_points, "step", "8 B per emitted contour point (SURVEY 8d), one launch per layer"),
         "stage04_trace": (["k_trace", "k_write_walks"], K * px + 8 * n_points, "step",

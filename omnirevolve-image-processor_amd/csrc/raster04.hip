@@ -156,6 +156,94 @@ static int excl_scan(orip_ctx* c, const T* in, T* out, size_t n, DBuf& tmp) {
     return 0;
 }
 
+// ---- thinning_zhangsuen (04:35-99) and the state bytes on bit planes: one bit per pixel, 64 pixels per word, blockIdx.z = layer.
+// The reference numbers the neighbours from the south (P2 = (y+1, x), then clockwise as seen with y down: SW, W, NW, N, NE, E, SE);
+// A(p) counts transitions around the same cycle wherever it starts, B(p) is symmetric, only the two product conditions differ from
+// the usual orientation.  Bit-sliced evaluation as in stage 08-B (vector08.hip: k_zs_bits).
+__global__ __launch_bounds__(256) void k_bytes_to_bits04(const u8* __restrict__ src, unsigned long long* __restrict__ bits, int H, int W, int Ww) {
+    const size_t nw = (size_t)H * Ww, w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (w0 >= nw) return;
+    const u8* s = src + (size_t)H * W * blockIdx.z; unsigned long long* b = bits + nw * blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    unsigned long long mine = 0;
+    for (int j = 0; j < 64; j++) {
+        const size_t wi = w0 + j; bool fg = false;
+        if (wi < nw) { const int y = (int)(wi / Ww), x = (int)(wi % Ww) * 64 + lane; fg = x < W && s[(size_t)y * W + x] != 0; }
+        const unsigned long long m = __ballot(fg);
+        if (lane == j) mine = m;
+    }
+    if (w0 + lane < nw) b[w0 + lane] = mine;
+}
+struct Nb8 { unsigned long long N, NE, E, SE, S, SW, W, NW; };
+__device__ __forceinline__ Nb8 neighbour_planes(const unsigned long long* __restrict__ s, int H, int Ww, int y, int xw, unsigned long long M) {
+    auto W64 = [&](int yy, int xx) -> unsigned long long { return (yy < 0 || yy >= H || xx < 0 || xx >= Ww) ? 0ULL : s[(size_t)yy * Ww + xx]; };
+    const unsigned long long U = W64(y - 1, xw), UL = W64(y - 1, xw - 1), UR = W64(y - 1, xw + 1), ML = W64(y, xw - 1), MR = W64(y, xw + 1);
+    const unsigned long long D = W64(y + 1, xw), DL = W64(y + 1, xw - 1), DR = W64(y + 1, xw + 1);
+    Nb8 n; n.N = U; n.NE = (U >> 1) | (UR << 63); n.E = (M >> 1) | (MR << 63); n.SE = (D >> 1) | (DR << 63);
+    n.S = D; n.SW = (D << 1) | (DL >> 63); n.W = (M << 1) | (ML >> 63); n.NW = (U << 1) | (UL >> 63);
+    return n;
+}
+// bit-sliced neighbour count: b0 ones, b1 twos, b2 fours, b3 eights
+__device__ __forceinline__ void count8(const Nb8& n, unsigned long long& b0, unsigned long long& b1, unsigned long long& b2, unsigned long long& b3) {
+    auto FA = [](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long& sum, unsigned long long& carry) { const unsigned long long t = a ^ b; sum = t ^ c; carry = (a & b) | (t & c); };
+    unsigned long long s1, c1, s2, c2, s4, c4, s5, c5;
+    FA(n.N, n.NE, n.E, s1, c1); FA(n.SE, n.S, n.SW, s2, c2);
+    const unsigned long long s3 = n.W ^ n.NW, c3 = n.W & n.NW;
+    FA(s1, s2, s3, s4, c4); FA(c1, c2, c3, s5, c5);
+    const unsigned long long c6 = s5 & c4;
+    b0 = s4; b1 = s5 ^ c4; b2 = c5 ^ c6; b3 = c5 & c6;
+}
+__global__ __launch_bounds__(256) void k_thin_bits04(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int H, int Ww, int sub, int* __restrict__ changed) {
+    const size_t nw = (size_t)H * Ww, wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nw) return;
+    const unsigned long long* s = src + nw * blockIdx.z; unsigned long long* d = dst + nw * blockIdx.z;
+    const unsigned long long M = s[wi];
+    if (!M) { d[wi] = 0; return; }
+    const Nb8 n = neighbour_planes(s, H, Ww, (int)(wi / Ww), (int)(wi % Ww), M);
+    unsigned long long b0, b1, b2, b3; count8(n, b0, b1, b2, b3);
+    const unsigned long long Bok = (b1 | b2) & ~b3 & ~(b2 & b1 & b0);          // 2 <= B <= 6
+    const unsigned long long P2 = n.S, P3 = n.SW, P4 = n.W, P5 = n.NW, P6 = n.N, P7 = n.NE, P8 = n.E, P9 = n.SE;
+    unsigned long long one = 0, two = 0;
+    auto TR = [&](unsigned long long a, unsigned long long b) { const unsigned long long t = ~a & b; two |= one & t; one |= t; };
+    TR(P2, P3); TR(P3, P4); TR(P4, P5); TR(P5, P6); TR(P6, P7); TR(P7, P8); TR(P8, P9); TR(P9, P2);
+    const unsigned long long cnd = sub == 0 ? (~(P2 & P4 & P6) & ~(P4 & P6 & P8)) : (~(P2 & P4 & P8) & ~(P2 & P6 & P8));
+    const unsigned long long del = M & (one & ~two) & Bok & cnd;
+    if (del) *changed = 1;
+    d[wi] = M & ~del;
+}
+// skeleton bytes (0 / 255) and state bytes (ST_FG | ST_END for degree 1 | ST_JUN for degree >= 3) from the thinned bit planes
+__global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long long* __restrict__ bits, u8* __restrict__ skel, u8* __restrict__ st, int H, int W, int Ww) {
+    const size_t nw = (size_t)H * Ww, w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (w0 >= nw) return;
+    const unsigned long long* s = bits + nw * blockIdx.z;
+    u8* sk = skel + (size_t)H * W * blockIdx.z; u8* so = st + (size_t)H * W * blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    unsigned long long fg = 0, en = 0, ju = 0;
+    if (w0 + lane < nw) {
+        const size_t wi = w0 + lane;
+        fg = s[wi];
+        if (fg) {
+            const Nb8 n = neighbour_planes(s, H, Ww, (int)(wi / Ww), (int)(wi % Ww), fg);
+            unsigned long long b0, b1, b2, b3; count8(n, b0, b1, b2, b3);
+            en = fg & b0 & ~b1 & ~b2 & ~b3;                   // exactly one neighbour
+            ju = fg & (b2 | b3 | (b1 & b0));                  // three or more
+        }
+    }
+    auto bc = [&](unsigned long long v, int j) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
+    };
+    for (int j = 0; j < 64; j++) {
+        const size_t wi = w0 + j; if (wi >= nw) break;
+        const unsigned long long f = bc(fg, j), e = bc(en, j), q = bc(ju, j);
+        const int y = (int)(wi / Ww), x = (int)(wi % Ww) * 64 + lane;
+        if (x < W) {
+            const bool on = (f >> lane) & 1ULL;
+            sk[(size_t)y * W + x] = on ? 255 : 0;
+            so[(size_t)y * W + x] = on ? (u8)(ST_FG | (((e >> lane) & 1ULL) ? ST_END : 0) | (((q >> lane) & 1ULL) ? ST_JUN : 0)) : (u8)0;
+        }
+    }
+}
+
 // State kept between orip_contours_prepare and the per-layer trace calls (device buffers live in lane 0's scratch).
 struct Prep04 {
     bool ready = false;
@@ -208,7 +296,26 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     HIPC(c, LN(c).flags.ensure(1024));
     int* d_changed = LN(c).flags.as<int>() + 8;
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K), block(256);
-    {
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
+    HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
+    if (!getenv("ORIP_THIN_BYTES")) {
+        // bit planes: 2 MB per 4096^2 layer; pack, iterate, then skeleton and state bytes in one unpacking pass
+        const int Ww = (W + 63) >> 6; const size_t nw = (size_t)H * Ww;
+        HIPC(c, LN(c).vtmp[10].ensure(nw * K * 16 + 64));
+        unsigned long long* bA = LN(c).vtmp[10].as<unsigned long long>(); unsigned long long* bB = bA + nw * K;
+        dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);
+        hipLaunchKernelGGL(k_bytes_to_bits04, gw, block, 0, LN(c).stream, c->edges.as<u8>(), bA, H, W, Ww);
+        for (int it = 0; it < 120; it++) {
+            HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
+            { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_changed); }
+            { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bB, bA, H, Ww, 1, d_changed); }
+            int h_changed = 0;
+            HIPC(c, hipMemcpyAsync(&h_changed, d_changed, 4, hipMemcpyDeviceToHost, LN(c).stream));
+            HIPC(c, hipStreamSynchronize(LN(c).stream));
+            if (!h_changed) break;
+        }
+        { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_bits_to_skel_state, gw, block, 0, LN(c).stream, bA, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W, Ww); }
+    } else {
         // iteration 1 reads the edges; ping-pong skel <-> tmpB so that the result always lands in skel
         const u8* cur = c->edges.as<u8>();
         for (int it = 0; it < 120; it++) {
@@ -221,13 +328,11 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
             HIPC(c, hipStreamSynchronize(LN(c).stream));
             if (!h_changed) break;
         }
+        { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     }
-    // ---- components, state bytes
-    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
+    // ---- components
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
     ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
-    HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
-    { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     // ---- ordered compaction
     const int nblk = cdiv(n, 1024);
     HIPC(c, LN(c).tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
