@@ -724,7 +724,8 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
     for (int i = 0; i < std::max(close_iters, 0); i++) passes.push_back(0);
     if (passes.empty()) passes.push_back(-1);   // identity copy via 1x1 "erode"
     // binary input (label masks always are; explicit masks are checked): the chain runs on bit planes
-    bool binary = labels_mode;
+    const bool have_bits = !labels_mode && c->mask_bits != nullptr && src == c->masks.as<u8>() && !getenv("ORIP_MORPH_BYTES");   // stage 02 left them
+    bool binary = labels_mode || have_bits;
     if (!binary && !getenv("ORIP_MORPH_BYTES")) {
         int* d_flag = LN(c).flags.as<int>() + 12;
         HIPC(c, hipMemsetAsync(d_flag, 0, 4, LN(c).stream));
@@ -737,7 +738,9 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
         HIPC(c, c->tmpA.ensure(std::max(plane * K, nw * K * 16 + 64)));
         unsigned long long* A = c->tmpA.as<unsigned long long>(); unsigned long long* B = A + nw * K;
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K), block(256);
-        hipLaunchKernelGGL(k_bits_pack, gw, block, 0, LN(c).stream, src, A, H, W, Ww, labels_mode ? 1 : 0);
+        if (have_bits) { if (c->mask_bits == (const void*)B) std::swap(A, B); }        // the planes are already there (first or second half)
+        else hipLaunchKernelGGL(k_bits_pack, gw, block, 0, LN(c).stream, src, A, H, W, Ww, labels_mode ? 1 : 0);
+        c->mask_bits = nullptr;
         for (size_t i = 0; i < passes.size(); i++) {
             ProfScope ps(c, "k_morph_bits");
             hipLaunchKernelGGL(k_morph_bits, gw, block, 0, LN(c).stream, A, B, H, W, Ww, k, se, passes[i] == 1 ? 1 : 0);
@@ -745,8 +748,10 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
         }
         hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
         HIPC(c, hipGetLastError());
+        if (labels_mode && dst == c->masks.as<u8>()) c->mask_bits = A;      // stage 03 can start from the bit planes
         return 0;
     }
+    c->mask_bits = nullptr;                       // the byte passes ping-pong through tmpA
     HIPC(c, c->tmpA.ensure(plane * K));
     dim3 grid(cdiv(W, MT_X), cdiv(H, MT_Y), K), block(256);
     const u8* cur = src; bool lm = labels_mode;
@@ -771,6 +776,7 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
 // ------------------------------------------------------------------------------------------------
 extern "C" int orip_set_image(orip_ctx* c, const uint8_t* bgr, int H, int W) {
     orip_enter(c);
+    c->mask_bits = nullptr;
     if (!bgr || H <= 0 || W <= 0) ORIP_FAIL(c, "bad image %dx%d", W, H);
     ORIP_TRY(orip_raster02_lab_tables(c));
     c->H = H; c->W = W;
@@ -796,6 +802,7 @@ extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* 
 extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
                                float* centers_out, double* compactness_out) {
     orip_enter(c);
+    c->mask_bits = nullptr;
     if (!c->image.p) ORIP_FAIL(c, "no image set");
     if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range 1..%d", K, ORIP_MAX_LAYERS);
     int64_t N = sample_idx ? n_idx : (int64_t)c->H * c->W;
@@ -895,6 +902,7 @@ extern "C" int orip_get_mask(orip_ctx* c, int layer, uint8_t* out) {
 }
 extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, int W) {
     orip_enter(c);
+    c->mask_bits = nullptr;
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->masks.ensure((size_t)H * W * K));
@@ -904,6 +912,7 @@ extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, i
 
 extern "C" int orip_keep_layers(orip_ctx* c, const int32_t* layers, int n) {
     orip_enter(c);
+    c->mask_bits = nullptr;
     if (!c->masks.p || n < 1 || n > c->K) ORIP_FAIL(c, "bad layer subset (n=%d, K=%d)", n, c->K);
     size_t plane = (size_t)c->H * c->W;
     for (int i = 0; i < n; i++) {
