@@ -96,7 +96,7 @@ __device__ float pairwise_subtree(const float* __restrict__ leafsum, int64_t s0,
 // one numpy leaf (8 <= n <= 128 elements from s) summed by 8 lanes: lane j owns accumulator r[j]; the xor tree reproduces
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (float addition commutes), the n % 8 tail is added in order
 template <int KIND>
-__device__ __forceinline__ float pairwise_leaf_g8(const int32_t* __restrict__ xy, int64_t s, int64_t n, int j) {
+__device__ __forceinline__ float pairwise_leaf_g8(const int32_t* xy, int64_t s, int64_t n, int j) {
     auto el = [&](int64_t i) { return KIND == 0 ? vs::seg_len_f32(xy, s + i) : vs::seg_hypot_f32(xy, s + i); };
     const int64_t lim = n - (n % 8);
     float r = el(j);
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
     __shared__ float part[2 << ORIP_PW_DEPTH];
+    __shared__ int2 stage[2048 + 64 + 130 + 8];
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = order[rr];               // longest first: a block that draws a long polyline late would be the tail of the launch
         PolyFeat f = out[i];
@@ -124,10 +125,21 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
         const int tid = threadIdx.x;
         int x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1]; double arc = 0.0;
         const bool closed_arc = (what & 4) != 0, any_arc = (what & 12) != 0;
+        const int2* P2 = reinterpret_cast<const int2*>(p);
+        if (!any_arc) {
+            // bounding box only: four independent 8-byte loads per turn keep the memory pipeline busy (the loop is latency-bound otherwise)
+            int64_t k = tid;
+            for (; k + 768 < n; k += 1024) {
+                const int2 a = P2[k], b = P2[k + 256], cc = P2[k + 512], d = P2[k + 768];
+                x0 = min(min(x0, a.x), min(min(b.x, cc.x), d.x)); x1 = max(max(x1, a.x), max(max(b.x, cc.x), d.x));
+                y0 = min(min(y0, a.y), min(min(b.y, cc.y), d.y)); y1 = max(max(y1, a.y), max(max(b.y, cc.y), d.y));
+            }
+            for (; k < n; k += 256) { const int2 a = P2[k]; x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
+        } else
         for (int64_t k = tid; k < n; k += 256) {
             int x = p[2 * k], y = p[2 * k + 1];
             x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
-            if (any_arc) {
+            {
                 int64_t pk = k == 0 ? (closed_arc ? n - 1 : 0) : k - 1;
                 float dx = (float)x - (float)p[2 * pk], dy = (float)y - (float)p[2 * pk + 1];
                 arc += (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
@@ -144,12 +156,22 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
             const int64_t ns = n - 1;               // number of segments
             float* ls = leafbuf + (off[i] >> 6) + 2 * i;
             const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group and turn
-            for (int64_t pm = (int64_t)grp * 64; pm < ns; pm += 32 * 64) {
-                int64_t s = 0, len = ns;
-                while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
-                if (((s + 63) >> 6) << 6 == pm) {   // every multiple of 64 lies in exactly one leaf; its first one owns the leaf
-                    float v = (what & 1) ? pairwise_leaf_g8<0>(p, s, len, j) : pairwise_leaf_g8<1>(p, s, len, j);
-                    if (j == 0) ls[pm >> 6] = v;
+            // a turn covers the 32 multiples of 64 in [r0, r0 + 2048): the leaves that own them lie inside [r0 - 63, r0 + 2047 + 128],
+            // so that stretch of points is staged in LDS by all threads (independent coalesced loads) and the groups sum from there
+            for (int64_t r0 = 0; r0 < ns; r0 += 32 * 64) {
+                const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);       // points [lo, hi)
+                __syncthreads();
+                for (int64_t q = lo + tid; q < hi; q += 256) stage[q - lo] = reinterpret_cast<const int2*>(p)[q];
+                __syncthreads();
+                const int64_t pm = r0 + (int64_t)grp * 64;
+                if (pm < ns) {
+                    int64_t s = 0, len = ns;
+                    while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
+                    if (((s + 63) >> 6) << 6 == pm) {   // every multiple of 64 lies in exactly one leaf; its first one owns the leaf
+                        const int32_t* sp = reinterpret_cast<const int32_t*>(stage) - 2 * lo;        // sp[2 * k] = x of point k
+                        float v = (what & 1) ? pairwise_leaf_g8<0>(sp, s, len, j) : pairwise_leaf_g8<1>(sp, s, len, j);
+                        if (j == 0) ls[pm >> 6] = v;
+                    }
                 }
             }
             __threadfence_block();
