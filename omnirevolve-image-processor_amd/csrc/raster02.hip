@@ -443,19 +443,44 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
                         long long bs = kmb_block_sum(cs, red);
                         if (tid == 0) G->blockpart[bid] = bs;
                         km_grid_sync(G);
-                        if (bid == 0 && tid == 0) {
-                            long long run = 0; int ci = N - 1; int b;
-                            for (b = 0; b < KMB_B; b++) { long long v = *(volatile long long*)&G->blockpart[b]; if ((double)(run + v) >= p) break; run += v; }
-                            if (b < KMB_B) {
-                                int t;
-                                for (t = 0; t < KMB_T; t++) { long long v = *(volatile long long*)&parts[b * KMB_T + t]; if ((double)(run + v) >= p) break; run += v; }
-                                if (t < KMB_T) {
-                                    int l2 = min(N, (b * KMB_T + t) * chunk), h2 = min(N, l2 + chunk);
-                                    for (int i = l2; i < h2; i++) { run += dist[i]; if ((double)run >= p) { ci = i; break; } }
+                        if (bid == 0 && tid < 64) {
+                            // first wave of block 0 descends: block totals, the threads of the crossing block, then the samples of the crossing
+                            // chunk; every test is "(double)(inclusive integer prefix) >= p" on exact integers, as in the scalar descent
+                            auto wave_incl = [&](long long v) { for (int o = 1; o < 64; o <<= 1) { long long t = __shfl_up(v, o, 64); if (tid >= o) v += t; } return v; };
+                            auto first_cross = [&](long long base, long long v, bool valid, long long& before) -> int {   // lane index of the first crossing, -1: none
+                                const long long inc = wave_incl(valid ? v : 0);
+                                const unsigned long long m = __ballot(valid && (double)(base + inc) >= p);
+                                const int f = m ? __ffsll((long long)m) - 1 : -1;
+                                const int src = f >= 0 ? f : 63;
+                                const long long incf = __shfl(inc, src, 64), vf = __shfl(valid ? v : 0, src, 64);
+                                before = base + (f >= 0 ? incf - vf : incf);        // prefix in front of the crossing lane / whole window when none
+                                return f;
+                            };
+                            long long run = 0; int ci = N - 1;
+                            int b = -1;
+                            for (int b0 = 0; b0 < KMB_B && b < 0; b0 += 64) {
+                                long long before; const bool valid = b0 + tid < KMB_B;
+                                const int f = first_cross(run, valid ? *(volatile long long*)&G->blockpart[b0 + tid] : 0, valid, before);
+                                run = before; if (f >= 0) b = b0 + f;
+                            }
+                            if (b >= 0) {
+                                int t = -1;
+                                for (int t0 = 0; t0 < KMB_T && t < 0; t0 += 64) {
+                                    long long before;
+                                    const int f = first_cross(run, *(volatile long long*)&parts[b * KMB_T + t0 + tid], true, before);
+                                    run = before; if (f >= 0) t = t0 + f;
+                                }
+                                if (t >= 0) {
+                                    const int l2 = min(N, (b * KMB_T + t) * chunk), h2 = min(N, l2 + chunk);
+                                    for (int i0 = l2; i0 < h2 && ci == N - 1; i0 += 64) {
+                                        long long before; const bool valid = i0 + tid < h2;
+                                        const int f = first_cross(run, valid ? (long long)dist[i0 + tid] : 0, valid, before);
+                                        run = before; if (f >= 0) { ci = i0 + f; break; }
+                                    }
                                 }
                             }
                             if (ci > N - 1) ci = N - 1;
-                            G->ci = ci;
+                            if (tid == 0) G->ci = ci;
                         }
                         km_grid_sync(G);
                         const int ci = *(volatile int*)&G->ci;
