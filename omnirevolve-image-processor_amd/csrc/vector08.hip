@@ -585,6 +585,32 @@ __global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, in
     }
 }
 __global__ __launch_bounds__(256) void k_ccl2_flatten(const u8* __restrict__ s, int* __restrict__ L, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n && s[i]) L[i] = ufind(L, i); }
+// the same union-find driven from the thinned bit plane: a thread owns a 64-pixel word, returns at once when it is empty (the
+// skeleton fills ~1 % of the canvas) and walks its set bits otherwise.  mode 0: init, 1: merge, 2: flatten.
+__global__ __launch_bounds__(256) void k_ccl2_bits(const unsigned long long* __restrict__ bits, int* __restrict__ L, int H, int W, int Ww, int mode) {
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= (size_t)H * Ww) return;
+    unsigned long long m = bits[wi];
+    if (!m) return;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww), x0 = xw * 64;
+    if (mode != 1) {
+        while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; const int id = y * W + x0 + j; L[id] = mode == 0 ? id : ufind(L, id); }
+        return;
+    }
+    const unsigned long long cur = m;
+    const unsigned long long left = xw > 0 ? bits[wi - 1] : 0ULL;
+    unsigned long long U = 0, UL = 0, UR = 0;
+    if (y > 0) { U = bits[wi - Ww]; if (xw > 0) UL = bits[wi - Ww - 1]; if (xw + 1 < Ww) UR = bits[wi - Ww + 1]; }
+    const unsigned long long hasW = (cur << 1) | (left >> 63), hasNW = (U << 1) | (UL >> 63), hasNE = (U >> 1) | (UR << 63);
+    while (m) {
+        const int j = __ffsll((long long)m) - 1; m &= m - 1;
+        const int id = y * W + x0 + j;
+        if ((hasW >> j) & 1ULL) uunite(L, id, id - 1);
+        if ((hasNW >> j) & 1ULL) uunite(L, id, id - W - 1);
+        if ((U >> j) & 1ULL) uunite(L, id, id - W);
+        if ((hasNE >> j) & 1ULL) uunite(L, id, id - W + 1);
+    }
+}
 // ordered compaction of skeleton pixels (count / write), 1024 px per block
 __global__ __launch_bounds__(256) void k_sk_count(const u8* __restrict__ s, int64_t n, unsigned* __restrict__ counts) {
     __shared__ unsigned ws[4];
@@ -1175,9 +1201,16 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         // components
         HIPC(c, LN(c).vtmp[10].ensure(Np * 4 + 64));
         int* L2 = LN(c).vtmp[10].as<int>();
+        if (!getenv("ORIP_THIN_BYTES")) {      // bA holds the thinned bit plane
+            const dim3 gwd((unsigned)cdiv((int64_t)nwords, 256));
+            hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 0);
+            { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 1); }
+            hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 2);
+        } else {
         hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp);
         { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp); }
         hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, skA, L2, (int)Np);
+        }
         tick("c:ccl");
         const int nblk = cdiv((int64_t)Np, 1024);
         HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
