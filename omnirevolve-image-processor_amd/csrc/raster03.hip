@@ -199,6 +199,44 @@ __global__ __launch_bounds__(256) void k_ccl16(const u8* __restrict__ img, int* 
         }
     }
 }
+// components of bit planes (one bit per pixel, 64 per word, blockIdx.z = layer): a thread owns a word, returns at once when it is
+// empty and walks its set bits otherwise.  Same ids (block raster) and the same union-find as above.  mode 0 init, 1 merge, 2 flatten.
+__global__ __launch_bounds__(256) void k_ccl_bits(const unsigned long long* __restrict__ bits, int* __restrict__ par, int H, int W, int Ww, int mode) {
+    const size_t nw = (size_t)H * Ww, wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nw) return;
+    const unsigned long long* b = bits + nw * blockIdx.z;
+    unsigned long long m = b[wi];
+    if (!m) return;
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1;
+    int* L = par + (size_t)Wb * Hb * 4 * blockIdx.z;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww), x0 = xw * 64;
+    if (mode != 1) {
+        while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; const int id = px_id(y, x0 + j, Wb); L[id] = mode == 0 ? id : uf_find(L, id); }
+        return;
+    }
+    const unsigned long long left = xw > 0 ? b[wi - 1] : 0ULL;
+    unsigned long long U = 0, UL = 0, UR = 0;
+    if (y > 0) { U = b[wi - Ww]; if (xw > 0) UL = b[wi - Ww - 1]; if (xw + 1 < Ww) UR = b[wi - Ww + 1]; }
+    const unsigned long long hasW = (m << 1) | (left >> 63), hasNW = (U << 1) | (UL >> 63), hasNE = (U >> 1) | (UR << 63);
+    while (m) {
+        const int j = __ffsll((long long)m) - 1; m &= m - 1;
+        const int x = x0 + j, id = px_id(y, x, Wb);
+        if ((hasW >> j) & 1ULL) uf_unite(L, id, px_id(y, x - 1, Wb));
+        if ((hasNW >> j) & 1ULL) uf_unite(L, id, px_id(y - 1, x - 1, Wb));
+        if ((U >> j) & 1ULL) uf_unite(L, id, px_id(y - 1, x, Wb));
+        if ((hasNE >> j) & 1ULL) uf_unite(L, id, px_id(y - 1, x + 1, Wb));
+    }
+}
+int orip_ccl_bits(orip_ctx* c, const unsigned long long* bits, int* par, int K) {
+    const int H = c->H, W = c->W, Ww = (W + 63) >> 6;
+    dim3 g((unsigned)cdiv((int64_t)H * Ww, 256), 1, K), block(256);
+    { ProfScope ps(c, "k_ccl_init"); hipLaunchKernelGGL(k_ccl_bits, g, block, 0, LN(c).stream, bits, par, H, W, Ww, 0); }
+    { ProfScope ps(c, "k_ccl_bits"); hipLaunchKernelGGL(k_ccl_bits, g, block, 0, LN(c).stream, bits, par, H, W, Ww, 1); }
+    { ProfScope ps(c, "k_ccl_flatten"); hipLaunchKernelGGL(k_ccl_bits, g, block, 0, LN(c).stream, bits, par, H, W, Ww, 2); }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value) {
     int H = c->H, W = c->W;
     dim3 grid(cdiv(W, 64), cdiv(H, 4), K), block(256);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 int orip_ccl(orip_ctx* c, const u8* img, int* par, int K, int bg_value);
+int orip_ccl_bits(orip_ctx* c, const unsigned long long* bits, int* par, int K);
 
 // ------------------------------------------------------------------------------------------------
 // Thinning.  P2..P9 offsets (dy,dx) derived from the _shift() arguments at 04:53-55.
@@ -330,9 +331,10 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         }
         { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     }
-    // ---- components
+    // ---- components (from the thinned bit planes when they exist)
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
-    ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
+    if (!getenv("ORIP_THIN_BYTES") && !getenv("ORIP_CCL_BYTES")) ORIP_TRY(orip_ccl_bits(c, LN(c).vtmp[10].as<unsigned long long>(), c->tmpD.as<int>(), K));
+    else ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
     // ---- ordered compaction
     const int nblk = cdiv(n, 1024);
     HIPC(c, LN(c).tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
