@@ -97,6 +97,7 @@ struct orip_ctx {
     DBuf tmpA, tmpB, tmpC, tmpD;   // raster scratch
     DBuf lab_tabs;  // u16 gamma[256] + u16 cbrt[3072] + i32 coeffs[9]
     bool tabs_ready = false;
+    const void* edge_bits = nullptr;   // bit planes of `edges` left in lane 0's scratch by stage 03 (nullptr: not available); consumed by stage 04
     const void* mask_bits = nullptr;   // bit planes of `masks` left in tmpA by stage 02 (nullptr: not available); consumed by stage 03
     // vector state
     DPolys polys[ORIP_SLOT_COUNT][ORIP_MAX_LAYERS];

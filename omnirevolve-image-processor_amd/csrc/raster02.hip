@@ -937,6 +937,7 @@ extern "C" int orip_set_masks(orip_ctx* c, const uint8_t* masks, int K, int H, i
 
 extern "C" int orip_keep_layers(orip_ctx* c, const int32_t* layers, int n) {
     orip_enter(c);
+    c->edge_bits = nullptr;
     c->mask_bits = nullptr;
     if (!c->masks.p || n < 1 || n > c->K) ORIP_FAIL(c, "bad layer subset (n=%d, K=%d)", n, c->K);
     size_t plane = (size_t)c->H * c->W;

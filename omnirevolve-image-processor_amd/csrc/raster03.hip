@@ -23,7 +23,8 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur_sobel_nms(const u8* __restrict__ masks, u8* __restrict__ map, int H, int W, int gk, int low, int high) {
+__global__ __launch_bounds__(256) void k_blur_sobel_nms(const u8* __restrict__ masks, u8* __restrict__ map, int H, int W, int gk, int low, int high,
+                                                        unsigned long long* __restrict__ cand_bits, unsigned long long* __restrict__ strong_bits, int Ww) {
     __shared__ u8 M[ET_Y + 2 * EH_MAX][ET_X + 2 * EH_MAX];
     __shared__ u8 B[ET_Y + 4][ET_X + 4];
     __shared__ short MAG[ET_Y + 2][ET_X + 2];
@@ -74,29 +75,38 @@ __global__ __launch_bounds__(256) void k_blur_sobel_nms(const u8* __restrict__ m
         MAG[ty][tx] = (short)m;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ET_Y * ET_X; i += blockDim.x) {
+    for (int i = threadIdx.x; i < ET_Y * ET_X; i += blockDim.x) {       // a wave = one row of the tile (ET_X == 64)
         int ty = i / ET_X, tx = i % ET_X;
         int y = y0 + ty, x = x0 + tx;
-        if (y >= H || x >= W) continue;
-        int by = ty + 2, bx = tx + 2;
-        int xs = ((int)B[by - 1][bx + 1] + 2 * (int)B[by][bx + 1] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by][bx - 1] + (int)B[by + 1][bx - 1]);
-        int ys = ((int)B[by + 1][bx - 1] + 2 * (int)B[by + 1][bx] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by - 1][bx] + (int)B[by - 1][bx + 1]);
-        int my = ty + 1, mx = tx + 1;
-        int m = MAG[my][mx];
+        const bool in = y < H && x < W;
         u8 res = 1;
-        if (m > low) {
-            int ax = abs(xs), ay = abs(ys) << 15;
-            int tg22x = ax * 13573;
-            bool keep;
-            if (ay < tg22x) keep = (m > MAG[my][mx - 1] && m >= MAG[my][mx + 1]);
-            else {
-                int tg67x = tg22x + (ax << 16);
-                if (ay > tg67x) keep = (m > MAG[my - 1][mx] && m >= MAG[my + 1][mx]);
-                else { int s = ((xs ^ ys) < 0) ? -1 : 1; keep = (m > MAG[my - 1][mx - s] && m > MAG[my + 1][mx + s]); }
+        if (in) {
+            int by = ty + 2, bx = tx + 2;
+            int xs = ((int)B[by - 1][bx + 1] + 2 * (int)B[by][bx + 1] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by][bx - 1] + (int)B[by + 1][bx - 1]);
+            int ys = ((int)B[by + 1][bx - 1] + 2 * (int)B[by + 1][bx] + (int)B[by + 1][bx + 1]) - ((int)B[by - 1][bx - 1] + 2 * (int)B[by - 1][bx] + (int)B[by - 1][bx + 1]);
+            int my = ty + 1, mx = tx + 1;
+            int m = MAG[my][mx];
+            if (m > low) {
+                int ax = abs(xs), ay = abs(ys) << 15;
+                int tg22x = ax * 13573;
+                bool keep;
+                if (ay < tg22x) keep = (m > MAG[my][mx - 1] && m >= MAG[my][mx + 1]);
+                else {
+                    int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = (m > MAG[my - 1][mx] && m >= MAG[my + 1][mx]);
+                    else { int s = ((xs ^ ys) < 0) ? -1 : 1; keep = (m > MAG[my - 1][mx - s] && m > MAG[my + 1][mx + s]); }
+                }
+                if (keep) res = (m > high) ? 2 : 0;
             }
-            if (keep) res = (m > high) ? 2 : 0;
+            if (map) dst[(size_t)y * W + x] = res;
         }
-        dst[(size_t)y * W + x] = res;
+        if (cand_bits) {          // candidate (weak or strong) and strong planes, one word per wave
+            const unsigned long long cm = __ballot(in && res != 1), sm = __ballot(in && res == 2);
+            if ((threadIdx.x & 63) == 0 && y < H) {
+                const size_t w = (size_t)H * Ww * blockIdx.z + (size_t)y * Ww + (x0 >> 6);
+                cand_bits[w] = cm; strong_bits[w] = sm;
+            }
+        }
     }
 }
 
@@ -277,6 +287,42 @@ __global__ __launch_bounds__(256) void k_hyst_out(const u8* __restrict__ map, co
     edges[o] = v;
 }
 
+// hysteresis on bit planes: roots of components that hold a strong pixel, then edge = candidate whose root is marked
+__global__ __launch_bounds__(256) void k_hyst_bits_mark(const unsigned long long* __restrict__ strong_bits, const int* __restrict__ par, u8* __restrict__ strong_root, int H, int W, int Ww) {
+    const size_t nw = (size_t)H * Ww, wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nw) return;
+    unsigned long long m = strong_bits[nw * blockIdx.z + wi];
+    if (!m) return;
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
+    const int y = (int)(wi / Ww), x0 = (int)(wi % Ww) * 64;
+    while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; strong_root[pplane * blockIdx.z + par[pplane * blockIdx.z + px_id(y, x0 + j, Wb)]] = 1; }
+}
+__global__ __launch_bounds__(256) void k_hyst_bits_out(const unsigned long long* __restrict__ cand_bits, const int* __restrict__ par, const u8* __restrict__ strong_root,
+                                                        unsigned long long* __restrict__ edge_bits, int H, int W, int Ww) {
+    const size_t nw = (size_t)H * Ww, wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nw) return;
+    unsigned long long m = cand_bits[nw * blockIdx.z + wi], e = 0;
+    if (m) {
+        const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
+        const int y = (int)(wi / Ww), x0 = (int)(wi % Ww) * 64;
+        while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; if (strong_root[pplane * blockIdx.z + par[pplane * blockIdx.z + px_id(y, x0 + j, Wb)]]) e |= 1ULL << j; }
+    }
+    edge_bits[nw * blockIdx.z + wi] = e;
+}
+__global__ __launch_bounds__(256) void k_bits_to_bytes03(const unsigned long long* __restrict__ bits, u8* __restrict__ dst, int H, int W, int Ww) {
+    const size_t nw = (size_t)H * Ww, w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (w0 >= nw) return;
+    const unsigned long long* b = bits + nw * blockIdx.z; u8* d = dst + (size_t)H * W * blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mine = (w0 + lane < nw) ? b[w0 + lane] : 0ULL;
+    for (int j = 0; j < 64; j++) {
+        const size_t wi = w0 + j; if (wi >= nw) break;
+        const unsigned long long v = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+        const int y = (int)(wi / Ww), xx = (int)(wi % Ww) * 64 + lane;
+        if (xx < W) d[(size_t)y * W + xx] = ((v >> lane) & 1ULL) ? 255 : 0;
+    }
+}
+
 extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int close_iters, int gauss_k, int low, int high) {
     orip_enter(c);
     if (!c->masks.p || c->K < 1) ORIP_FAIL(c, "no masks resident (run orip_extract_layers or orip_set_masks)");
@@ -288,11 +334,31 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
     HIPC(c, c->tmpC.ensure(plane * K));   // NMS map
     ORIP_TRY(orip_morph_open_close(c, c->masks.as<u8>(), c->tmpB.as<u8>(), K, 2, morph_k, open_iters, close_iters, false));
     dim3 grid(cdiv(W, ET_X), cdiv(H, ET_Y), K), block(256);
-    { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), c->tmpC.as<u8>(), H, W, gauss_k, low, high); }
-    HIPC(c, hipGetLastError());
     int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; size_t pplane = (size_t)Wb * Hb * 4;
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
     HIPC(c, LN(c).tmpE.ensure(pplane * K));
+    c->edge_bits = nullptr;
+    if (!getenv("ORIP_CCL_BYTES")) {
+        // candidates are ~2 % of the pixels: NMS leaves two bit planes (candidate, strong); components, strong roots and edges are
+        // computed from words; the edge bit planes stay for stage 04's thinning
+        const int Ww = (W + 63) >> 6; const size_t nw = (size_t)H * Ww;
+        HIPC(c, LN(c).vtmp[11].ensure(nw * K * 16 + 64));
+        HIPC(c, LN(c).vtmp[10].ensure(nw * K * 16 + 64));
+        unsigned long long* cand = LN(c).vtmp[11].as<unsigned long long>(); unsigned long long* strong = cand + nw * K;
+        unsigned long long* ebits = LN(c).vtmp[10].as<unsigned long long>();
+        { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), (u8*)nullptr, H, W, gauss_k, low, high, cand, strong, Ww); }
+        ORIP_TRY(orip_ccl_bits(c, cand, c->tmpD.as<int>(), K));
+        HIPC(c, hipMemsetAsync(LN(c).tmpE.p, 0, pplane * K, LN(c).stream));
+        dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);
+        { ProfScope ps(c, "k_hyst_mark"); hipLaunchKernelGGL(k_hyst_bits_mark, gw, block, 0, LN(c).stream, strong, c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), H, W, Ww); }
+        { ProfScope ps(c, "k_hyst_out"); hipLaunchKernelGGL(k_hyst_bits_out, gw, block, 0, LN(c).stream, cand, c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), ebits, H, W, Ww); }
+        hipLaunchKernelGGL(k_bits_to_bytes03, gw, block, 0, LN(c).stream, ebits, c->edges.as<u8>(), H, W, Ww);
+        HIPC(c, hipGetLastError());
+        c->edge_bits = ebits;
+        return 0;
+    }
+    { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), c->tmpC.as<u8>(), H, W, gauss_k, low, high, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0); }
+    HIPC(c, hipGetLastError());
     ORIP_TRY(orip_ccl(c, c->tmpC.as<u8>(), c->tmpD.as<int>(), K, 1));
     HIPC(c, hipMemsetAsync(LN(c).tmpE.p, 0, pplane * K, LN(c).stream));
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K);
@@ -312,6 +378,7 @@ extern "C" int orip_get_edges(orip_ctx* c, int layer, uint8_t* out) {
 }
 extern "C" int orip_set_edges(orip_ctx* c, const uint8_t* edges, int K, int H, int W) {
     orip_enter(c);
+    c->edge_bits = nullptr;
     if (K < 1 || K > ORIP_MAX_LAYERS || H <= 0 || W <= 0) ORIP_FAIL(c, "bad shape");
     c->H = H; c->W = W; c->K = K;
     HIPC(c, c->edges.ensure((size_t)H * W * K));

@@ -305,7 +305,8 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         HIPC(c, LN(c).vtmp[10].ensure(nw * K * 16 + 64));
         unsigned long long* bA = LN(c).vtmp[10].as<unsigned long long>(); unsigned long long* bB = bA + nw * K;
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);
-        hipLaunchKernelGGL(k_bytes_to_bits04, gw, block, 0, LN(c).stream, c->edges.as<u8>(), bA, H, W, Ww);
+        if (c->edge_bits != (const void*)bA) hipLaunchKernelGGL(k_bytes_to_bits04, gw, block, 0, LN(c).stream, c->edges.as<u8>(), bA, H, W, Ww);   // stage 03 may have left them
+        c->edge_bits = nullptr;
         for (int it = 0; it < 120; it++) {
             HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
             { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_changed); }
