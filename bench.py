@@ -41,7 +41,7 @@ def kernel_groups(H, W, K, n_points):
         "morph_pass": (["k_morph_pass"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and pass (byte kernel: non-binary masks only)"),
         "morph_bits": (["k_morph_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and pass; the bit planes (2 MB per layer) stay in L2, "
                        "so this is cache traffic, not HBM traffic"),
-        "blur_sobel_nms": (["k_blur_sobel_nms"], 2 * K * px, "launch", "1 B mask in + 1 B NMS map out per pixel per layer"),
+        "blur_sobel_nms": (["k_blur_sobel_nms"], K * px + K * px // 4, "launch", "1 B mask in + 2 bits (candidate, strong planes) out per pixel per layer"),
         "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration (byte kernel, ORIP_THIN_BYTES only)"),
         "thin_bits": (["k_thin_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and sub-iteration; bit planes of 2 MB per layer: cache traffic"),
         "ccl_merge": (["k_ccl_merge"], 5 * K * px, "launch", "1 B image + 4 B parent per pixel per layer"),
