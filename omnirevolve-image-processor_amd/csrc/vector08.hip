@@ -138,9 +138,11 @@ __device__ __forceinline__ int64_t ub_u32v(const unsigned* a, int64_t n, unsigne
     return lo;
 }
 struct SampleArrs { double* sx; double* sy; double* dprev; int* xi; int* yi; unsigned* rank; uint8_t* inc; };
+// 32-bit cell key (column, row) of the point hash (A5); computed while the samples are produced
+__device__ __forceinline__ unsigned cell_key32(long long cx, long long cy) { return ((unsigned)((cx + 32768) & 0xffff) << 16) | (unsigned)((cy + 32768) & 0xffff); }
 __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
-                                                  unsigned MS, double step, int W, int H, SampleArrs A) {
+                                                  unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     int64_t r = ub_u32v(sbase, n_rank, g) - 1;
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off
     A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
     bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
     A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
+    ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g;
 }
 
 // distance of every sample to its predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
@@ -1050,7 +1053,10 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
             SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.dprev = A.sy + MS; A.xi = (int*)(A.dprev + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
             unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
-            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A); }
+            HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
+            unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
+            const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
+            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
@@ -1108,10 +1114,6 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
             tick("caps");
             // ---- A5: (polyline, cell) buckets in pop order
-            HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
-            unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
-            const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
-            hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, MS, inv, ckin, cvin);
             {
                 ProfScope ps(c, "sort_cells");
                 size_t bytes = 0;
