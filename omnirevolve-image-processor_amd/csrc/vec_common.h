@@ -45,7 +45,7 @@ struct PolyFeat {
     uint8_t closed;             // first == last on the ORIGINAL polyline (n >= 2)
 };
 
-#define ORIP_LONG_POLY 2048
+#define ORIP_LONG_POLY 512
 // what: bit0 perimeter KIND0, bit1 perimeter KIND1 (hypot), bit2 arcLength closed, bit3 arcLength open, bit4 open view (_ensure_open)
 __global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
                                                         PolyFeat* __restrict__ out) {
