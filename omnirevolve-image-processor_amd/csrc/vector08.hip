@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict
 }
 
 // ================================================================= A2: resample (08:53-64)
+#define ORIP_LONG_CUM 128      // polylines above this many points get a wavefront for their cumulative lengths (k_cumlen_long)
 struct RsInfo { int64_t n_eff; double total; unsigned m; unsigned pass; };
 // sequential float32 cumsum per polyline (np.cumsum): one lane per short polyline; long polylines (k_cumlen_long) use one
 // wavefront: 64 segment lengths are computed / loaded by the lanes, the strictly sequential chain of float adds then runs
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off,
     if (n >= 2) {
         if (n > 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;    // _is_closed inside _resample_arclen (08:56)
         r.n_eff = n;
-        if (n <= ORIP_LONG_POLY) {
+        if (n <= ORIP_LONG_CUM) {
             float acc = 0.f; s[0] = 0.f;
             for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32(p, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
             rs_finish(r, acc, n, step);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ 
         const int64_t i = ord[rr];                 // longest perimeter first: the long chains start at once, the short ones fill in behind
         RsInfo r = info[i];
         const int64_t n = r.n_eff;
-        if (n <= ORIP_LONG_POLY) continue;
+        if (n <= ORIP_LONG_CUM) continue;
         const int32_t* p = pts + 2 * off[i]; float* s = cum + off[i];
         const int64_t nseg = n - 1;
         float acc = 0.f;
@@ -1041,7 +1042,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
-        if (kept0.p.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info, ord); }
+        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info, ord); }
         tick("cumlen");
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
