@@ -183,3 +183,37 @@ def test_empty_and_degenerate_edges(dev):
     e = np.zeros((1, 9, 20), np.uint8); e[0, 4, 2:18] = 255    # a straight line touching nothing
     dev.set_edges(e); dev.find_contours()
     assert same_polys(dev.get_polys(SLOT_CONTOURS, 0), O.stage04(e[0]))
+
+
+ODD_SHAPES = [(1, 1), (1, 70), (70, 1), (2, 2), (3, 63), (5, 64), (5, 65), (17, 127), (33, 129), (64, 191), (9, 257)]
+
+
+@pytest.mark.parametrize("shape", ODD_SHAPES)
+def test_stage04_odd_shapes(dev, shape):
+    """Widths around the 64-pixel word boundaries of the bit planes, one-pixel-wide and one-pixel-high edge maps, several
+    densities (dense maps exercise thinning, sparse ones the isolated-pixel and short-path rules)."""
+    from orip.lib import SLOT_CONTOURS
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    dens = [0.08, 0.35, 0.7, 1.0]
+    e = np.stack([(rng.random((H, W)) < d).astype(np.uint8) * 255 for d in dens])
+    dev.set_edges(e)
+    dev.find_contours()
+    for l in range(len(dens)):
+        want = O.stage04(e[l])
+        got = dev.get_polys(SLOT_CONTOURS, l)
+        assert same_polys(got, want), (shape, dens[l], len(got), len(want))
+
+
+@pytest.mark.parametrize("shape", ODD_SHAPES)
+def test_stage03_odd_shapes(dev, shape):
+    H, W = shape
+    rng = np.random.default_rng(H * 77 + W)
+    from scipy.ndimage import gaussian_filter
+    masks = np.stack([(gaussian_filter(rng.standard_normal((H, W)), 1.5, mode="nearest") > t).astype(np.uint8) * 255 for t in (-0.1, 0.0, 0.1)])
+    cfg = dict(O.DEFAULTS)
+    dev.set_masks(masks)
+    dev.detect_edges(cfg["edge_morph_kernel"], cfg["edge_morph_open_iters"], cfg["edge_morph_close_iters"],
+                     O.ensure_odd(cfg["edge_kernel_size"]), cfg["edge_low_threshold"], cfg["edge_high_threshold"])
+    for k in range(3):
+        assert np.array_equal(dev.get_edges(k), O.stage03(masks[k], cfg)), (shape, k)

@@ -250,3 +250,45 @@ def test_full_chain_vs_oracle(dev, case):
                 assert (a["x"], a["y"]) == (b["x"], b["y"]), n
     dg, tg = O.path_length(ops); dw, tw = O.path_length(want["ops"])
     assert abs(dg + tg - dw - tw) <= 1e-3 * (dw + tw)      # north_star: plotted path length within 1e-3 relative
+
+
+# ---------------------------------------------------------------- edge cases (inputs in tests/edge_cases.py)
+import edge_cases as E
+
+_CFG08 = dict(O.DEFAULTS, pixels_per_mm=6)
+
+
+@pytest.mark.parametrize("name", sorted(E.cases08(*O.canvas_size(_CFG08))))
+def test_stage08_edge_cases(dev, name):
+    """Empty / degenerate / duplicated / off-canvas inputs of the intra-layer dedup."""
+    from orip import stages as S
+    polys = E.cases08(*O.canvas_size(_CFG08))[name]
+    want_l, want_t = O.stage08_layer(polys, O.derived08(_CFG08))
+    got_l, got_t = S.dedup_layer(polys, _cfgobj(_CFG08), dev)
+    assert got_t == want_t, name
+    assert same_polys(got_l, want_l), (name, len(got_l), len(want_l))
+
+
+@pytest.mark.parametrize("name", sorted(E.cases07()))
+def test_stage07_edge_cases(dev, name):
+    """One polyline, identical polylines (every distance ties), counts around the 64-polyline switch to the grid search."""
+    from orip import stages as S
+    polys = E.cases07()[name]
+    assert same_polys(S.sort_contours(polys, dev), O.sort07(polys)), name
+
+
+def test_stage10_edge_cases(dev):
+    """A layer without lines, a layer with taps only, a layer repeating the darker layer's lines (all of it is cut away)."""
+    from orip import stages as S
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=6, color_names=["layer_dark", "layer_mid", "x_extra", "layer_light"])
+    rng = np.random.default_rng(12)
+    base = _rand_polys(rng, 30, lo=2, hi=25, span=1100, step=40, closed_p=0.0)
+    intra = {"layer_dark": (base, _taps(rng.integers(0, 1200, (10, 2)))),
+             "layer_mid": ([], []),
+             "x_extra": ([], _taps(rng.integers(0, 1200, (15, 2)))),
+             "layer_light": ([p.copy() for p in base] + _rand_polys(rng, 5, lo=2, hi=25, span=1100, step=40, closed_p=0.0), [])}
+    want = O.stage10(intra, cfgd)
+    got = S.dedup_cross(intra, _cfgobj(cfgd), dev)
+    for n in cfgd["color_names"]:
+        assert got[n][1] == want[n][1], n
+        assert same_polys(got[n][0], want[n][0]), n
