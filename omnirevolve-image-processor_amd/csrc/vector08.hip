@@ -114,13 +114,14 @@ __global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ 
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
-                float pre = 0.f;
+                // the strictly sequential float chain p[j] = p[j-1] + d[j] as 63 wave-shifted adds: after step j lane j is final, and a
+                // final lane recomputes the same sum from its final neighbour at every later step (lane 0 reads 0 and keeps 0 + d'[0])
+                float d = (lane == 0) ? __fadd_rn(acc, cur[w]) : cur[w];      // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
+                float pre = d;
 #pragma unroll
-                for (int j = 0; j < 64; j++) {
-                    float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[w]), j));
-                    acc = __fadd_rn(acc, v);          // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
-                    pre = (lane == j) ? acc : pre;
-                }
+                for (int j = 1; j < 64; j++)
+                    pre = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pre), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), d);
+                acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre), 63));      // padding lanes add +0: lane 63 holds the last real sum
                 if (k < nseg) s[k + 1] = pre;
             }
             lengths(ra, rb, cur);

@@ -13,6 +13,8 @@ def cases08(W, H):
     c["crossing_border"] = [P([[-200, 100], [W + 200, 140]]), P([[300, -300], [340, H + 300]]), P([[W - 3, H - 3], [W + 40, H + 40]])]
     c["closed_loops"] = [P([[200, 200], [600, 200], [600, 600], [200, 600], [200, 200]]), P([[203, 201], [598, 203], [601, 597], [199, 602], [203, 201]])]
     c["spiral_self_overlap"] = [P([[int(500 + (5 + t * 0.4) * np.cos(t / 6)), int(500 + (5 + t * 0.4) * np.sin(t / 6))] for t in range(600)])]
+    t = np.arange(5000)
+    c["long_polyline_5000"] = [P(np.stack([600 + 0.11 * t * np.cos(t / 37.0), 800 + 0.13 * t * np.sin(t / 41.0)], 1).astype(np.int32)), line]
     return c
 def cases07():
     rng = np.random.default_rng(3)
