@@ -142,26 +142,56 @@ __device__ __forceinline__ int64_t ub_u32v(const unsigned* a, int64_t n, unsigne
 struct SampleArrs { double* sx; double* sy; double* dprev; int* xi; int* yi; unsigned* rank; uint8_t* inc; };
 // 32-bit cell key (column, row) of the point hash (A5); computed while the samples are produced
 __device__ __forceinline__ unsigned cell_key32(long long cx, long long cy) { return ((unsigned)((cx + 32768) & 0xffff) << 16) | (unsigned)((cy + 32768) & 0xffff); }
+// rank (polyline) and segment of sample g, as k_samples needs them.  Both are monotone in g, so the values of the first sample of a
+// 256-sample block and of the next block bound the searches of every sample in between: k_sample_hints does the two full binary
+// searches once per block, k_samples only searches between the hints (mostly zero to a few steps instead of ~28 dependent loads).
+__device__ __forceinline__ int64_t sample_rank(const unsigned* __restrict__ sbase, const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t lo, int64_t hi, unsigned g) {
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (sbase[mid] <= g) lo = mid + 1; else hi = mid; }      // first rank in [lo, hi) whose base is > g
+    int64_t r = lo - 1;
+    while (info[ord[r]].m == 0) r--;
+    return r;
+}
+__device__ __forceinline__ float sample_t(unsigned j, double step) {
+    float t0 = 0.0f, t1 = (float)(0.0 + step), delta = __fsub_rn(t1, t0);
+    return j == 0 ? t0 : (j == 1 ? t1 : __fadd_rn(t0, __fmul_rn((float)j, delta)));
+}
+// searchsorted(s, t, 'right') - 1 on s[0..n_eff), clipped to [0, n_eff-2], given klo <= result <= khi
+__device__ __forceinline__ int64_t sample_seg(const float* __restrict__ s, int64_t n_eff, double t, int64_t klo, int64_t khi) {
+    int64_t lo = klo + 1, hi = khi + 2;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((double)s[mid] <= t) lo = mid + 1; else hi = mid; }
+    int64_t k = lo - 1; if (k < 0) k = 0; if (k > n_eff - 2) k = n_eff - 2;
+    return k;
+}
+__global__ __launch_bounds__(256) void k_sample_hints(const int64_t* __restrict__ off, const float* __restrict__ cum, const RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
+                                                       const unsigned* __restrict__ sbase, int64_t n_rank, unsigned MS, double step, unsigned nb, int2* __restrict__ hints) {
+    unsigned b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const unsigned g = b * 256u;
+    int64_t r = sample_rank(sbase, info, ord, 0, n_rank, g);
+    unsigned i = ord[r]; RsInfo ri = info[i];
+    int64_t k = 0;
+    if (!ri.pass) k = sample_seg(cum + off[i], ri.n_eff, (double)sample_t(g - sbase[r], step), -1, ri.n_eff - 2);
+    hints[b] = make_int2((int)r, (int)k);
+}
 __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
-                                                  unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals) {
+                                                  unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
+                                                  const int2* __restrict__ hints) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
-    int64_t r = ub_u32v(sbase, n_rank, g) - 1;
-    while (info[ord[r]].m == 0) r--;
+    const int2 h0 = hints[blockIdx.x];
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
+    int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
     unsigned i = ord[r]; unsigned j = g - sbase[r];
     const int32_t* p = pts + 2 * off[i]; const float* s = cum + off[i];
     RsInfo ri = info[i];
     double x, y;
     if (ri.pass) { x = (double)(float)p[2 * j]; y = (double)(float)p[2 * j + 1]; }
     else {
-        float t0 = 0.0f, t1 = (float)(0.0 + step), delta = __fsub_rn(t1, t0);
-        float tf = j == 0 ? t0 : (j == 1 ? t1 : __fadd_rn(t0, __fmul_rn((float)j, delta)));
-        double t = (double)tf;
-        // searchsorted(s, t, 'right') - 1 on s[0..n_eff), clipped to [0, n_eff-2]
-        int64_t lo = 0, hi = ri.n_eff;
-        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((double)s[mid] <= t) lo = mid + 1; else hi = mid; }
-        int64_t k = lo - 1; if (k < 0) k = 0; if (k > ri.n_eff - 2) k = ri.n_eff - 2;
+        double t = (double)sample_t(j, step);
+        const int64_t klo = (r == h0.x) ? h0.y : -1, khi = (!last && r == h1.x) ? h1.y : ri.n_eff - 2;
+        int64_t k = sample_seg(s, ri.n_eff, t, klo, khi);
         double sk = (double)s[k], sk1 = (double)s[k + 1];
         double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
         double a = __dsub_rn(1.0, u);
@@ -1055,10 +1085,13 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             HIPC(c, LN(c).vtmp[3].ensure((size_t)MS * (8 + 8 + 8 + 4 + 4 + 4 + 1 + 4 + 4 + 8 + 1) + 1024));
             SampleArrs A; A.sx = LN(c).vtmp[3].as<double>(); A.sy = A.sx + MS; A.dprev = A.sy + MS; A.xi = (int*)(A.dprev + MS); A.yi = A.xi + MS; A.rank = (unsigned*)(A.yi + MS);
             unsigned* npop = A.rank + MS; int* capprev = (int*)(npop + MS); int2* spt = (int2*)(capprev + MS + (MS & 1)); A.inc = (uint8_t*)(spt + MS); uint8_t* sflag = A.inc + MS;
-            HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64));
+            const unsigned nb = (unsigned)cdiv(MS, 256);
+            HIPC(c, LN(c).vtmp[5].ensure((size_t)MS * 24 + 64 + (size_t)(nb + 1) * 8));
             unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
-            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin); }
+            int2* hints = (int2*)(LN(c).vtmp[5].as<uint8_t>() + (((size_t)MS * 24 + 63) & ~(size_t)63));
+            hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), cum, info, ord, sbase, nk, MS, step, nb, hints);
+            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(nb), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin, hints); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
