@@ -135,15 +135,21 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
                 y0 = min(min(y0, a.y), min(min(b.y, cc.y), d.y)); y1 = max(max(y1, a.y), max(max(b.y, cc.y), d.y));
             }
             for (; k < n; k += 256) { const int2 a = P2[k]; x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
-        } else
-        for (int64_t k = tid; k < n; k += 256) {
-            int x = p[2 * k], y = p[2 * k + 1];
-            x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
-            {
-                int64_t pk = k == 0 ? (closed_arc ? n - 1 : 0) : k - 1;
-                float dx = (float)x - (float)p[2 * pk], dy = (float)y - (float)p[2 * pk + 1];
+        } else {
+            // arc length next to the bounding box: the same four-loads-in-flight shape; a thread adds its terms in the order of its k
+            auto seg = [&](int64_t k, const int2 a, const int2 b) {       // b: predecessor of point k
+                x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y);
+                float dx = (float)a.x - (float)b.x, dy = (float)a.y - (float)b.y;
                 arc += (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            };
+            auto pred = [&](int64_t k) -> int64_t { return k == 0 ? (closed_arc ? n - 1 : 0) : k - 1; };
+            int64_t k = tid;
+            for (; k + 768 < n; k += 1024) {
+                const int2 a0 = P2[k], a1 = P2[k + 256], a2 = P2[k + 512], a3 = P2[k + 768];
+                const int2 b0 = P2[pred(k)], b1 = P2[k + 255], b2 = P2[k + 511], b3 = P2[k + 767];
+                seg(k, a0, b0); seg(k + 256, a1, b1); seg(k + 512, a2, b2); seg(k + 768, a3, b3);
             }
+            for (; k < n; k += 256) seg(k, P2[k], P2[pred(k)]);
         }
         rx0[tid] = x0; rx1[tid] = x1; ry0[tid] = y0; ry1[tid] = y1; rarc[tid] = arc;
         __syncthreads();
@@ -158,11 +164,21 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
             const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group and turn
             // a turn covers the 32 multiples of 64 in [r0, r0 + 2048): the leaves that own them lie inside [r0 - 63, r0 + 2047 + 128],
             // so that stretch of points is staged in LDS by all threads (independent coalesced loads) and the groups sum from there
+            // the points of the NEXT turn are requested before the leaves of this turn are summed and only land in LDS after them
+            int2 nxt[9];
+            auto request = [&](int64_t r0) {
+                const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);
+#pragma unroll
+                for (int u = 0; u < 9; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2[q] : make_int2(0, 0); }
+            };
+            request(0);
             for (int64_t r0 = 0; r0 < ns; r0 += 32 * 64) {
                 const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);       // points [lo, hi)
                 __syncthreads();
-                for (int64_t q = lo + tid; q < hi; q += 256) stage[q - lo] = reinterpret_cast<const int2*>(p)[q];
+#pragma unroll
+                for (int u = 0; u < 9; u++) if (lo + tid + 256 * u < hi) stage[tid + 256 * u] = nxt[u];
                 __syncthreads();
+                if (r0 + 32 * 64 < ns) request(r0 + 32 * 64);
                 const int64_t pm = r0 + (int64_t)grp * 64;
                 if (pm < ns) {
                     int64_t s = 0, len = ns;
