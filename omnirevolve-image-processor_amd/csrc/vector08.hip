@@ -222,34 +222,56 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A, unsigned* __restrict__ npop, const unsigned* __restrict__ only) {
-    const int lane = threadIdx.x;
+    __shared__ double ring[2048];
+    __shared__ unsigned npst[1024 + 64];
+    const unsigned lane = threadIdx.x;
     for (int64_t r = blockIdx.x; r < n_rank; r += gridDim.x) {
         if (only && !only[r]) continue;       // only the polylines the parallel version could not decide
         const unsigned b = sbase[r], e = sbase[r + 1];
         if (e <= b) continue;
         const double* D = A.dprev + b; unsigned* NP = npop + b;
         const unsigned m = e - b;
-        unsigned head = 0, jw = 0, hw = 0;
-        double dj = (lane < (int)m) ? D[lane] : 0.0, dh = dj, djn = 0.0;
-        if (64 + lane < (int)m && 64u < m) djn = D[64 + lane];
+        // The distances pass through an LDS ring of two 1024-sample chunks (the chunk of j and the one before it) and the pop counts
+        // through an LDS stage: global memory is touched once per chunk, in bulk.  (Windows loaded from or stored to global memory
+        // inside the sample loop made the wave wait for a memory round trip every 64 samples: most of the kernel's time.)  The 64-value
+        // windows the recurrence picks from come out of the ring; a head that trails by more than a chunk reads global memory.
+        constexpr unsigned C = 1024u, RM = 2u * C - 1u;
+        auto fill = [&](unsigned c0) {           // 16 independent loads per lane in flight, then the LDS writes (slots past m: the last value, never used)
+            double tmp[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const unsigned idx = c0 + lane + 64u * u; tmp[u] = D[idx < m ? idx : m - 1]; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) ring[(c0 + lane + 64u * u) & RM] = tmp[u];
+        };
+        auto flush = [&](unsigned c0, unsigned cnt) { for (unsigned t = lane; t < cnt; t += 64u) NP[c0 + t] = npst[t]; };
+        fill(0);
+        unsigned head = 0, jw = 0, hw = 0xffffffffu, cs = 0;
+        double dj = ring[lane], dh = 0.0;
         double tail_len = 0.0; unsigned nv = 0;
         for (unsigned j = 0; j < m; j++) {
-            if (j - jw == 64u) {                     // next push window (prefetched one window ahead)
-                NP[jw + lane] = nv;
-                jw += 64u; dj = djn;
-                djn = (jw + 64u + lane < m) ? D[jw + 64u + lane] : 0.0;
+            if (j - jw == 64u) {                     // next push window
+                npst[jw - cs + lane] = nv;
+                jw += 64u;
+                if (jw - cs == C) { flush(cs, C); cs += C; fill(cs); }
+                dj = ring[(jw + lane) & RM];
             }
             if (j > head) tail_len = __dadd_rn(tail_len, rl_f64(dj, (int)(j - jw)));
-            while (head <= j && __builtin_amdgcn_readfirstlane((int)(tail_len > tail_len_px))) {
+            while (head <= j && __builtin_amdgcn_ballot_w64(tail_len > tail_len_px) != 0) {
                 head++;
                 if (head <= j) {
-                    if (head - hw >= 64u) { hw = head & ~63u; dh = (hw + lane < m) ? D[hw + lane] : 0.0; }
-                    tail_len = __dsub_rn(tail_len, rl_f64(dh, (int)(head - hw)));
+                    const unsigned w = head & ~63u;
+                    if (w != hw) {
+                        hw = w;
+                        if (w + C >= cs) dh = ring[(w + lane) & RM];                       // the chunk of j or the one before it
+                        else { const unsigned idx = w + (unsigned)lane; dh = D[idx < m ? idx : m - 1]; }
+                    }
+                    tail_len = __dsub_rn(tail_len, rl_f64(dh, (int)(head - w)));
                 } else tail_len = 0.0;
             }
             nv = ((unsigned)lane == (j & 63u)) ? head : nv;
         }
-        if (jw + lane < m) NP[jw + lane] = nv;
+        npst[jw - cs + lane] = nv;
+        flush(cs, m - cs);
     }
 }
 // Parallel form of the same simulation.  After sample j is pushed the queue holds samples head..j and tail_len is the sum of the
