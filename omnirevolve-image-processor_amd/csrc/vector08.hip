@@ -338,8 +338,15 @@ __device__ __forceinline__ unsigned long long cap_key(int x0, int y0, int x1, in
     return ((a << 28) | b) + 1ULL;     // 0 is the empty marker
 }
 __device__ __forceinline__ unsigned long long hash64(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+// one 16-byte slot per capsule: key and first sequence number arrive in one memory sector (the table is far larger than the caches and
+// every probe is a random access: two arrays meant two sectors per probe)
+struct __attribute__((aligned(16))) CapSlot { unsigned long long key; unsigned val; unsigned pad; };
+__global__ __launch_bounds__(256) void k_caps_init(CapSlot* __restrict__ tab, unsigned long long tsize) {
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < tsize) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0u, 0u, 0xffffffffu, 0u);
+}
 __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigned* __restrict__ sbase, const int* __restrict__ capprev, unsigned MS,
-                                                      unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tvals, unsigned long long tmask, int max_probe, int* __restrict__ overflow) {
+                                                      CapSlot* tab, unsigned long long tmask, int max_probe, int* __restrict__ overflow) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     int cp = capprev[g];
@@ -349,20 +356,22 @@ __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigne
     unsigned long long h = hash64(key) & tmask;
     for (int probe = 0;; probe++) {
         if (probe >= max_probe) { *overflow = 1; return; }      // table too small for the number of distinct capsules: the host retries larger
-        unsigned long long cur = tkeys[h];
-        if (cur == 0) { unsigned long long old = atomicCAS(&tkeys[h], 0ULL, key); if (old == 0 || old == key) cur = key; else cur = old; }
-        if (cur == key) { if (*(volatile unsigned*)&tvals[h] > g) atomicMin(&tvals[h], g); return; }    // the minimum only decreases: a stale read can only cost a useless atomic
+        const uint4 s = *reinterpret_cast<const uint4*>(&tab[h]);      // key and value in one 16-byte load (every probe reads another slot)
+        unsigned long long cur = ((unsigned long long)s.y << 32) | s.x;
+        if (cur == 0) { unsigned long long old = atomicCAS(&tab[h].key, 0ULL, key); if (old == 0 || old == key) cur = key; else cur = old; }
+        if (cur == key) { if (s.z > g) atomicMin(&tab[h].val, g); return; }    // the minimum only decreases: a stale read can only cost a useless atomic
         h = (h + 1) & tmask;
     }
 }
-__global__ __launch_bounds__(256) void k_caps_stamp(const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tvals, unsigned long long tsize,
+__global__ __launch_bounds__(256) void k_caps_stamp(const CapSlot* __restrict__ tab, unsigned long long tsize,
                                                      int rad, unsigned* __restrict__ firstseq, int W, int H) {
     const int lane = threadIdx.x & 63;
     const long long r2 = (long long)rad * rad;
     unsigned long long wave = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * 256) >> 6;
     for (unsigned long long s0 = wave * 64; s0 < tsize; s0 += nwaves * 64) {
-        unsigned long long k = (s0 + lane < tsize) ? tkeys[s0 + lane] : 0ULL;
-        unsigned v = k ? tvals[s0 + lane] : 0u;
+        const uint4 sl = (s0 + lane < tsize) ? reinterpret_cast<const uint4*>(tab)[s0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        unsigned long long k = ((unsigned long long)sl.y << 32) | sl.x;
+        unsigned v = sl.z;
         unsigned long long occ = __ballot(k != 0);
         while (occ) {
             int src = __ffsll((long long)occ) - 1; occ &= occ - 1;
@@ -1155,20 +1164,19 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             unsigned long long tfull = 1024; while (tfull < 2ull * MS) tfull <<= 1;
             unsigned long long tsize = 1024; while (tsize < MS / 4ull) tsize <<= 1;
             if (getenv("ORIP_CAPS_TINY")) tsize = 1024;            // test hook: exercise the growth path
-            unsigned long long* tkeys = nullptr; unsigned* tvals = nullptr;
+            CapSlot* tab = nullptr;
             int* d_ovf = LN(c).flags.as<int>() + 62;
             for (;; tsize = std::min(tfull, tsize * 4)) {
-                HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 12 + 64));
-                tkeys = LN(c).vtmp[4].as<unsigned long long>(); tvals = (unsigned*)(tkeys + tsize);
-                HIPC(c, hipMemsetAsync(tkeys, 0, (size_t)tsize * 8, LN(c).stream));
-                HIPC(c, hipMemsetAsync(tvals, 0xff, (size_t)tsize * 4, LN(c).stream));
+                HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 16 + 64));
+                tab = LN(c).vtmp[4].as<CapSlot>();
+                hipLaunchKernelGGL(k_caps_init, dim3((unsigned)cdiv(tsize, 256)), dim3(256), 0, LN(c).stream, tab, tsize);
                 HIPC(c, hipMemsetAsync(d_ovf, 0, 4, LN(c).stream));
                 const int max_probe = tsize >= tfull ? 0x7fffffff : 96;
-                { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tkeys, tvals, tsize - 1, max_probe, d_ovf); }
+                { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tab, tsize - 1, max_probe, d_ovf); }
                 int ovf = 0; ORIP_TRY(vread(c, &ovf, d_ovf));
                 if (!ovf) break;
             }
-            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tkeys, tvals, tsize, P.brush_forbid / 2, firstseq, W, H); }
+            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tab, tsize, P.brush_forbid / 2, firstseq, W, H); }
             tick("caps");
             // ---- A5: (polyline, cell) buckets in pop order
             {
