@@ -20,6 +20,7 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return -4;
     orip_ctx* c = new orip_ctx();
     c->device = device_id;
+    for (auto& o : c->lane_owner) o.store(0);
     for (auto& l : c->ln) {
         if (hipStreamCreate(&l.stream) != hipSuccess) { delete c; return -5; }
         hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
@@ -117,8 +118,7 @@ extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const
     else HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
     if (total) HIPC(c, hipMemcpyAsync(P.pts.p, pts, (size_t)total * 8, hipMemcpyHostToDevice, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
-    P.n = n; P.total = total;
-    if (layer >= c->K) c->K = layer + 1;
+    P.n = n; P.total = total;      // the raster layer count (c->K) is NOT touched: list slots are addressed up to ORIP_MAX_LAYERS
     return 0;
 }
 extern "C" int orip_taps_size(orip_ctx* c, int which, int layer, int64_t* n) {
@@ -143,6 +143,5 @@ extern "C" int orip_set_taps(orip_ctx* c, int which, int layer, int64_t n, const
     HIPC(c, T.xy.ensure((size_t)std::max<int64_t>(n, 1) * 8 + 64));
     if (n) { HIPC(c, hipMemcpyAsync(T.xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, LN(c).stream)); HIPC(c, hipStreamSynchronize(LN(c).stream)); }
     T.n = n;
-    if (layer >= c->K) c->K = layer + 1;
     return 0;
 }

@@ -8,6 +8,7 @@
 #include <vector>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include "../../include/orip.h"
 
 typedef uint8_t u8;
@@ -38,7 +39,11 @@ struct DBuf {
         void* np_ = nullptr;
         hipError_t e = hipMalloc(&np_, ncap);
         if (e != hipSuccess) return e;
-        if (keep && p && cap) { e = hipMemcpyAsync(np_, p, cap, hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return e; hipStreamSynchronize(s); }
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np_, p, cap, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { hipFree(np_); return e; }
+        }
         if (p) hipFree(p);
         p = np_; cap = ncap;
         return hipSuccess;
@@ -78,11 +83,23 @@ struct orip_ctx;
 void orip_enter(orip_ctx* c);
 #define ORIP_LANE_CROSS (ORIP_MAX_LAYERS + 1)
 void orip_contours_free(orip_ctx* c);
-struct LaneGuard { int prev; explicit LaneGuard(int lane) : prev(orip_tls_lane) { orip_tls_lane = lane; } ~LaneGuard() { orip_tls_lane = prev; } };
+// A lane (stream + scratch that grows with hipFree / hipMalloc) serves ONE call at a time: two host threads on one lane would free
+// buffers under each other's kernels (the r01 memory access fault of the sharded path: a stage-12 call addressed by the GLOBAL layer id
+// landed on the lane of another layer's running 04->08 pipeline).  LaneGuard claims the lane for the calling thread and the entry
+// points fail loudly when it is taken; nested claims of the lane the thread already holds are free.
+struct LaneGuard {
+    orip_ctx* c; int prev, lane; bool ok, owner;
+    LaneGuard(orip_ctx* ctx, int lane_id);
+    ~LaneGuard();
+};
+#define ORIP_LANE(ctx, lane_id)                                                                                              \
+    LaneGuard _lane_guard((ctx), (lane_id));                                                                                 \
+    if (!_lane_guard.ok) ORIP_FAIL(ctx, "lane %d is busy: another call is using this layer's stream and scratch", (int)(lane_id))
 
 struct orip_ctx {
     int device = 0;
     LaneRes ln[ORIP_MAX_LAYERS + 2];      // 0: raster stages; l + 1: layer l; ORIP_LANE_CROSS: stage 10
+    std::atomic<int> lane_owner[ORIP_MAX_LAYERS + 2];   // 1 while a call holds the lane (LaneGuard); lane 0 is not claimed
     orip_params10 p10{}; bool p10_ready = false;   // stage 10 between orip_dedup_cross_begin and the per-layer calls
     void* prep04 = nullptr;               // stage-04 state between orip_contours_prepare and orip_contours_layer (raster04.hip)
     std::mutex mu;
@@ -109,14 +126,22 @@ struct orip_ctx {
     std::map<std::string, ProfEntry> prof;
 };
 
+inline LaneGuard::LaneGuard(orip_ctx* ctx, int lane_id) : c(ctx), prev(orip_tls_lane), lane(lane_id), ok(true), owner(false) {
+    if (prev != lane) { int expect = 0; ok = c->lane_owner[lane].compare_exchange_strong(expect, 1); owner = ok; }
+    if (ok) orip_tls_lane = lane;
+}
+inline LaneGuard::~LaneGuard() { if (ok) orip_tls_lane = prev; if (owner) c->lane_owner[lane].store(0); }
+
 // Time one kernel launch with HIP events on ctx->stream when profiling is enabled (bench.py roofline leg).
 struct ProfScope {
     orip_ctx* c; const char* name;
-    ProfScope(orip_ctx* ctx, const char* n) : c(ctx), name(n) { if (c->prof_on) hipEventRecord(LN(c).ev0, LN(c).stream); }
+    bool armed = false;
+    ProfScope(orip_ctx* ctx, const char* n) : c(ctx), name(n) { if (c->prof_on) armed = hipEventRecord(LN(c).ev0, LN(c).stream) == hipSuccess; }
     ~ProfScope() {
-        if (!c->prof_on) return;
-        hipEventRecord(LN(c).ev1, LN(c).stream); hipEventSynchronize(LN(c).ev1);
-        float ms = 0; hipEventElapsedTime(&ms, LN(c).ev0, LN(c).ev1);
+        if (!armed) return;
+        float ms = 0;
+        if (hipEventRecord(LN(c).ev1, LN(c).stream) != hipSuccess || hipEventSynchronize(LN(c).ev1) != hipSuccess ||
+            hipEventElapsedTime(&ms, LN(c).ev0, LN(c).ev1) != hipSuccess) return;          // a failed timing is dropped, never recorded as 0 ms
         std::lock_guard<std::mutex> g(c->mu);
         auto& e = c->prof[name]; e.ms += ms; e.launches++;
     }

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
 struct Prep04 {
     bool ready = false;
     unsigned M = 0, NC = 0;
+    int K = 0;                                      // layer count the schedule was built for (c->K may change afterwards)
     std::vector<unsigned> h_cs, layer_first;       // comp_start on the host; first component of every layer (+ sentinel)
     const unsigned* order = nullptr;                // components by (layer, size descending)
     WalkArgs A;                                     // shared arguments (state bytes, keys, lin, comp_start, memo, winfo, total_fg)
@@ -280,14 +281,14 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     if (H > 8192 || W > 8192) ORIP_FAIL(c, "image %dx%d exceeds the 8192x8192 limit of the component key packing", W, H);
     if (!c->prep04) c->prep04 = new Prep04();
     Prep04& R = *static_cast<Prep04*>(c->prep04);
-    R.ready = false;
+    R.ready = false; R.K = K;
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) { R.launched[l] = false; R.F[l] = 0; R.memo_clear[l] = false; }
     const size_t plane = (size_t)H * W; const int64_t n = (int64_t)plane * K;
     // the memo planes (one word per pixel and incoming direction, 0.5 GB per layer at 4096^2) are cleared on the layer lanes now,
     // underneath the raster work below, instead of in front of every layer's trace
     HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
     for (int l = 0; l < K; l++) {
-        LaneGuard lane(l + 1);
+        ORIP_LANE(c, l + 1);
         HIPC(c, hipMemsetAsync(c->ln[0].vtmp[6].as<unsigned>() + plane * 8 * l, 0, plane * 8 * 4, LN(c).stream));
         R.memo_clear[l] = true;
     }
@@ -512,9 +513,9 @@ extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
     orip_enter(c);
     Prep04* R = static_cast<Prep04*>(c->prep04);
     if (!R || !R->ready) ORIP_FAIL(c, "orip_contours_prepare has not run");
-    if (layer < 0 || layer >= c->K) ORIP_FAIL(c, "bad layer %d", layer);
+    if (layer < 0 || layer >= R->K) ORIP_FAIL(c, "bad layer %d (prepared for %d layers)", layer, R->K);
     if (R->M == 0 || R->layer_first[layer] == R->layer_first[layer + 1]) return 0;
-    LaneGuard lane(layer + 1);
+    ORIP_LANE(c, layer + 1);
     ORIP_TRY(trace_launch(c, *R, layer, 64));
     return trace_finish(c, *R, layer);
 }
@@ -525,8 +526,8 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     Prep04& R = *static_cast<Prep04*>(c->prep04);
     if (R.M == 0) return 0;
     // every layer's trace is enqueued on its own stream first, so the long serial walks of all layers overlap
-    for (int l = 0; l < c->K; l++) if (R.layer_first[l] != R.layer_first[l + 1]) { LaneGuard lane(l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
-    for (int l = 0; l < c->K; l++) if (R.launched[l]) { LaneGuard lane(l + 1); ORIP_TRY(trace_finish(c, R, l)); }
+    for (int l = 0; l < R.K; l++) if (R.layer_first[l] != R.layer_first[l + 1]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
+    for (int l = 0; l < R.K; l++) if (R.launched[l]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_finish(c, R, l)); }
     return 0;
 }
 

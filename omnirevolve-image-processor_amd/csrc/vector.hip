@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, 
 extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
     orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
-    LaneGuard lane(layer + 1);
+    ORIP_LANE(c, layer + 1);
     DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
     D.n = S.n; D.total = S.total;
     HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
@@ -36,7 +36,7 @@ extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, fl
 extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
     orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
-    LaneGuard lane(layer + 1);
+    ORIP_LANE(c, layer + 1);
     ORIP_TRY(vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void k_plot_order_wave(const PolyFeat* __restri
 extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t* n_ops) {
     orip_enter(c);
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
-    LaneGuard lane(layer + 1);
+    ORIP_LANE(c, layer + 1);
     DPolys& L = c->polys[ORIP_SLOT_LINES_CROSS][layer]; DTaps& T = c->taps[ORIP_TAPS_CROSS][layer];
     int64_t nl = L.n, nt = T.n;
     c->n_ops[layer] = 0; *n_ops = 0;

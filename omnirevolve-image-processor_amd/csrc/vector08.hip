@@ -1064,7 +1064,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (!prm || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
     const orip_params08 P = *prm;
     const int W = P.W, H = P.H;
-    LaneGuard lane(layer + 1);
+    ORIP_LANE(c, layer + 1);
     if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
     if (!(P.sample_step * 2.0 < P.max_jump)) ORIP_FAIL(c, "dedup_sample_step must be < max_join_jump_px / 2 (stage-A segments are assumed jump-free)");
     DPolys& S = c->polys[ORIP_SLOT_SORTED][layer]; DPolys& OUT = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DTaps& TOUT = c->taps[ORIP_TAPS_INTRA][layer];

@@ -370,7 +370,7 @@ extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
     const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
     const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));
     if (rad_lines > ORIP_PAD - 2 || rad_taps > 200) ORIP_FAIL(c, "brush radius %d/%d too large for the padded raster", rad_lines, rad_taps);
-    LaneGuard lane(ORIP_LANE_CROSS);
+    ORIP_LANE(c, ORIP_LANE_CROSS);
     HIPC(c, LN(c).canvas.ensure((size_t)W * H + 64));
     HIPC(c, hipMemsetAsync(LN(c).canvas.p, 0, (size_t)W * H, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
@@ -386,7 +386,7 @@ extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer
     if (!c->p10_ready) ORIP_FAIL(c, "orip_dedup_cross_begin has not run");
     const orip_params10 P = c->p10;
     const int W = P.W, H = P.H;
-    LaneGuard lane(ORIP_LANE_CROSS);
+    ORIP_LANE(c, ORIP_LANE_CROSS);
     const int Wp = W + 2 * ORIP_PAD, Hp = H + 2 * ORIP_PAD;
     const int rad_lines = (int)std::max<long long>(1, vs::round_half_even(P.D_lines)) / 2;
     const int rad_taps = (int)std::max<long long>(1, vs::round_half_even(P.D_taps / 2.0));

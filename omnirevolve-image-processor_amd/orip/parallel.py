@@ -108,6 +108,7 @@ def broadcast_layer(lists, owner: int, device=None) -> Lists:
 
 def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None):
     """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  Ops stay on the GPU.
+    world > 1: rank r ends with the lists and ops of its layers owned_layers(K, r, world) under local indices 0..len-1.
 
     world > 1: every rank pipelines its own layers (04 -> 08, one lane each).  Stage 10 is replicated and streamed: the
     layers are visited dark -> light; the owner of the next layer waits for its pipeline, broadcasts the layer's
@@ -137,7 +138,13 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
         ready, errors = S._start_fronts(S.layer_front(dev, cfg, W, H, 8), range(len(mine)), order_local)
     pool = S._get_pool()
     dev.dedup_cross_begin(S.params10(cfg))
-    stage_slot = _l.MAX_LAYERS - 1                   # remote layers pass through this spare slot (len(mine) <= MAX_LAYERS / 2)
+    # Every list of an owned layer lives under its LOCAL index i (CONTOURS ... LINES_CROSS, taps, ops) and all per-layer calls of
+    # that layer run on lane i + 1.  (r01 addressed stage 10's output and stage 12 by the global id g: orip_plot_order(g) then ran
+    # on the lane of local layer g -- a different layer whose 04->08 pipeline was still growing that lane's scratch buffers -- and
+    # the GPU faulted at full size.  The library now also refuses a second call on a busy lane.)
+    stage_slot = _l.MAX_LAYERS - 1                   # remote layers pass through this spare slot
+    if len(mine) >= _l.MAX_LAYERS:
+        raise ValueError(f"rank {rank} owns {len(mine)} layers: the spare slot {stage_slot} for remote layers would be one of them")
     tails = []
     for g in order:
         owner = g % world
@@ -149,13 +156,13 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
             broadcast_layer(lists, owner, coll_device)      # the other ranks are waiting in this collective: never skip it
             if failed:
                 continue
-            dev.dedup_cross_layer(g, src_layer=i)
-            tails.append(pool.submit(dev.plot_order, g, R))
+            dev.dedup_cross_layer(i, src_layer=i)
+            tails.append(pool.submit(dev.plot_order, i, R))
         else:
             lines, taps = broadcast_layer(None, owner, coll_device)
             dev.set_polys(_l.SLOT_LINES_INTRA, stage_slot, lines)
             dev.set_taps(_l.TAPS_INTRA, stage_slot, taps)
-            dev.dedup_cross_layer(g, src_layer=stage_slot)
+            dev.dedup_cross_layer(stage_slot, src_layer=stage_slot)
     n_ops = sum(len(f.result()) for f in tails)
     if errors:
         for e in ready.values():

@@ -71,6 +71,26 @@ def ensure_odd(n: int) -> int:  # 03:9-11
     return n if n % 2 == 1 else n + 1
 
 
+def lab8_to_bgr(lab_u8) -> Tuple[int, int, int]:
+    """_lab_to_bgr (02:58-61), the palette's approx_bgr: 8-bit Lab (L*255/100, a+128, b+128) -> BGR.  Host arithmetic on K triples
+    (a by-product for the previews): CIE L*a*b* -> XYZ (D65 white 0.950456 / 1 / 1.088754) -> linear sRGB -> gamma.
+    cv2 is not available to pin the last bit (parity unpinned); tests check it against the oracle's forward Lab tables."""
+    L = float(lab_u8[0]) * 100.0 / 255.0
+    fy = (L + 16.0) / 116.0
+    f = (fy + (float(lab_u8[1]) - 128.0) / 500.0, fy, fy - (float(lab_u8[2]) - 128.0) / 200.0)
+    xyz = []
+    for t, white in zip(f, (0.950456, 1.0, 1.088754)):
+        cube = t * t * t
+        xyz.append(white * (cube if cube > 0.008856 else (t - 16.0 / 116.0) / 7.787))
+    X, Y, Z = xyz
+    out = []
+    for m in ((0.055648, -0.204043, 1.057311), (-0.969256, 1.875991, 0.041556), (3.240479, -1.53715, -0.498535)):   # B, G, R rows
+        c = m[0] * X + m[1] * Y + m[2] * Z
+        c = 12.92 * c if c <= 0.0031308 else 1.055 * (max(c, 0.0) ** (1.0 / 2.4)) - 0.055
+        out.append(int(min(255, max(0, round(c * 255.0)))))
+    return out[0], out[1], out[2]
+
+
 # ---------------------------------------------------------------- derived parameter blocks
 def params08(cfg: Config) -> _l.Params08:  # 08:484-509 (SURVEY App. A.3)
     pen_diam = float(cfg.pen_width_px); pen_radius = float(cfg.pen_radius_px)

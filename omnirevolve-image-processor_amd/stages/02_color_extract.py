@@ -10,18 +10,6 @@ from orip import stages as S
 from orip.config import load_config
 
 
-def _lab8_to_bgr(lab):
-    """Approximate inverse of the 8-bit Lab encoding for the palette preview colour (a6 in SURVEY 8a; previews only)."""
-    L = lab[0] * 100.0 / 255.0; a = lab[1] - 128.0; b = lab[2] - 128.0
-    fy = (L + 16.0) / 116.0; fx = fy + a / 500.0; fz = fy - b / 200.0
-    def finv(t): return t ** 3 if t ** 3 > 0.008856 else (t - 16.0 / 116.0) / 7.787
-    X, Y, Z = 0.950456 * finv(fx), finv(fy), 1.088754 * finv(fz)
-    rgb = np.array([3.240479 * X - 1.53715 * Y - 0.498535 * Z, -0.969256 * X + 1.875991 * Y + 0.041556 * Z, 0.055648 * X - 0.204043 * Y + 1.057311 * Z])
-    rgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * np.clip(rgb, 0, None) ** (1 / 2.4) - 0.055)
-    r, g, bb = (int(np.clip(round(v * 255.0), 0, 255)) for v in rgb)
-    return bb, g, r
-
-
 def main():
     cfg = load_config()
     os.makedirs(cfg.output_dir, exist_ok=True)
@@ -40,7 +28,7 @@ def main():
         nz = int(np.count_nonzero(masks[name]))
         lab = info["centers_lab"][k]
         palette[name] = {"mode": "kmeans", "cluster_index": int(k), "cluster_lab": [int(v) for v in lab],
-                         "approx_bgr": list(_lab8_to_bgr(lab.astype(np.uint8).astype(np.float64))), "pixels": int(info["counts"][k]), "mask_nonzero": nz}
+                         "approx_bgr": list(S.lab8_to_bgr(lab.astype(np.uint8))), "pixels": int(info["counts"][k]), "mask_nonzero": nz}
         print(f"Extracted (kmeans): {name} | cluster={k} | L*={lab[0]:.1f} | pixels={int(info['counts'][k])} | nz={nz}")
     pal_path = os.path.join(cfg.output_dir, "palette_by_name.json")
     with open(pal_path, "w", encoding="utf-8") as f:

@@ -144,6 +144,31 @@ def bgr2lab(bgr: np.ndarray) -> np.ndarray:
     return out
 
 
+def lab8_to_bgr(lab_u8) -> Tuple[int, int, int]:
+    """_lab_to_bgr (02:58-61): cv2.cvtColor(1x1 Lab u8, COLOR_Lab2BGR).  PARITY UNPINNED (cv2 absent): restated as the
+    float inverse of the CIE L*a*b* D65 / sRGB transform OpenCV documents for Lab2BGR (L = v0*100/255, a = v1-128, b = v2-128;
+    fY = (L+16)/116, fX = fY + a/500, fZ = fY - b/200; t^3 above the 0.008856 knee, (t-16/116)/7.787 below; XYZ -> linear sRGB
+    with the inverse of the matrix the forward path uses; sRGB gamma; round to nearest, saturate).  OpenCV's own 8-bit path is a
+    fixed-point version of the same transform, so single-LSB differences are possible; the committed check is the round trip through
+    the forward tables of this oracle (tests/test_oracle_golden_pure.py::test_lab8_to_bgr_round_trip)."""
+    v = np.asarray(lab_u8, np.float64).reshape(3)
+    L = v[0] * 100.0 / 255.0; a = v[1] - 128.0; b = v[2] - 128.0
+    fy = (L + 16.0) / 116.0; fx = fy + a / 500.0; fz = fy - b / 200.0
+
+    def finv(t):
+        t3 = t * t * t
+        return t3 if t3 > 0.008856 else (t - 16.0 / 116.0) / 7.787
+
+    X, Y, Z = 0.950456 * finv(fx), finv(fy), 1.088754 * finv(fz)
+    lin = (3.240479 * X - 1.53715 * Y - 0.498535 * Z, -0.969256 * X + 1.875991 * Y + 0.041556 * Z, 0.055648 * X - 0.204043 * Y + 1.057311 * Z)
+
+    def gamma(c):
+        return 12.92 * c if c <= 0.0031308 else 1.055 * (max(c, 0.0) ** (1.0 / 2.4)) - 0.055
+
+    r, g, bb = (int(min(255, max(0, round(gamma(c) * 255.0)))) for c in lin)
+    return bb, g, r
+
+
 def kmeans(samples: np.ndarray, K: int, attempts=3, max_iter=40, eps=0.5) -> Tuple[np.ndarray, float]:
     s = np.ascontiguousarray(samples, np.float32).reshape(-1, 3)
     centers = np.zeros((K, 3), np.float32)

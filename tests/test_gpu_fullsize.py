@@ -1,5 +1,11 @@
-"""BASELINE.json's full configuration (4096 x 4096, 8 layers) through size-independent properties -- the oracle needs
-~17 minutes for this image, so nothing here calls it:
+"""BASELINE.json's full configuration (4096 x 4096, 8 layers).
+
+* test_c3_digests_vs_oracle: every artefact of every layer (labels, masks, edges, skeleton, contours, scaled, sorted, lines / taps
+  after 08 and after 10, ops) hashed on the device's output and compared with the SHA-256 digests the ORACLE produced for the same
+  image (tests/golden/c3_digests.json, written once in the build container by tests/golden/make_fullsize_digests.py: the oracle
+  needs ~20 minutes for this image, so it cannot run inside the test).  Bit-exact parity of the headline configuration.
+
+Size-independent properties, no oracle involved:
 
 * schedule independence: the per-layer pipelines (default), one-layer-at-a-time execution and the single-workgroup
   k-means must all produce byte-identical lines, taps and ops for every layer (checksums of every artefact);
@@ -99,3 +105,50 @@ def test_ops_are_a_permutation_of_lines_and_taps(setup):
         assert sorted(line_ops[:, 1].tolist()) == list(range(n_lines))
         assert sorted(map(tuple, tap_ops[:, 3:5].tolist())) == sorted(taps)
         assert np.array_equal(dev.plot_order(g, R), ops)                     # same input, same order
+
+
+def _sha_polys(off, pts):
+    h = hashlib.sha256(); h.update(np.ascontiguousarray(off, np.int64).tobytes()); h.update(np.ascontiguousarray(pts, np.int32).tobytes())
+    return {"n": int(len(off) - 1), "points": int(len(pts)), "sha256": h.hexdigest()}
+
+
+def _sha_taps(taps):
+    a = np.ascontiguousarray(np.asarray(list(taps), np.int32).reshape(-1, 2))
+    return {"n": int(len(a)), "sha256": hashlib.sha256(a.tobytes()).hexdigest()}
+
+
+def test_c3_digests_vs_oracle(setup):
+    """The headline configuration against the oracle: same image, same artefacts, same hash (see the module docstring)."""
+    import json
+    from orip import lib as L, parallel as P, stages as S
+    dev, cfg, img = setup
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_digests.json")) as f:
+        G = json.load(f)
+    assert G["config"]["H"] == H and G["config"]["W"] == W and G["config"]["K"] == K
+    assert hashlib.sha256(img.tobytes()).hexdigest() == G["image_sha256"]          # same synthetic image on this box
+    dev.set_image(img)
+    P.run_path_sharded(dev, cfg, H, W, 0, 1)
+    assert hashlib.sha256(dev.get_labels().tobytes()).hexdigest() == G["labels_sha256"]
+    names = S.cluster_names(cfg)
+    assert names == G["device_layer_names"]
+    R = S.r_insert12(cfg)
+    ops_all = {}
+    for l, n in enumerate(names):
+        want = G["layers"][n]
+        assert hashlib.sha256(dev.get_mask(l).tobytes()).hexdigest() == want["mask"], ("mask", n)
+        assert hashlib.sha256(dev.get_edges(l).tobytes()).hexdigest() == want["edges"], ("edges", n)
+        assert hashlib.sha256(dev.get_skeleton(l).tobytes()).hexdigest() == want["skeleton"], ("skeleton", n)
+        for key, slot in (("contours", L.SLOT_CONTOURS), ("scaled", L.SLOT_SCALED), ("sorted", L.SLOT_SORTED), ("lines_intra", L.SLOT_LINES_INTRA), ("lines_cross", L.SLOT_LINES_CROSS)):
+            off, pts = dev.get_polys_flat(slot, l)
+            got = _sha_polys(off, pts); del off, pts
+            assert got == want[key], (key, n, got, want[key])
+        assert _sha_taps(dev.get_taps(L.TAPS_INTRA, l)) == want["taps_intra"], ("taps_intra", n)
+        assert _sha_taps(dev.get_taps(L.TAPS_CROSS, l)) == want["taps_cross"], ("taps_cross", n)
+        raw = dev.plot_order(l, R)
+        assert {"n": int(len(raw)), "sha256": hashlib.sha256(np.ascontiguousarray(raw, np.int32).tobytes()).hexdigest()} == want["ops"], ("ops", n)
+        ops_all[n] = S.ops_from_device(dev, l, R)
+    # north_star parity quantity (iii): total plotted path length, computed as the oracle computes it (12:71-80)
+    from oracle import oracle as O
+    draw, travel = O.path_length(ops_all)
+    assert abs(draw - G["path_length_px"]["draw"]) <= 1e-3 * G["path_length_px"]["draw"]
+    assert abs(travel - G["path_length_px"]["travel"]) <= 1e-3 * G["path_length_px"]["travel"]

@@ -50,7 +50,22 @@ def test_pipeline_steps_2_to_12_on_disk(tmp_path):
     man = json.loads((out / "vector_manifest.json").read_text())
     assert man["image_size"] == [1260, 1782] and man["coords"] == "pixel_top_left" and [l["name"] for l in man["layers"]] == layer_names(K)
     pal = json.loads((out / "palette_by_name.json").read_text())
-    assert set(pal) == set(layer_names(K)) and all("approx_bgr" in v for v in pal.values())
+    assert set(pal) == set(layer_names(K))
+    # palette rows (02:159-167): integer cluster Lab (dark -> light), pixel counts, non-zero counts of the written masks, approx_bgr
+    counts = np.bincount(want["labels"].reshape(-1), minlength=K)
+    for k, n in enumerate(layer_names(K)):
+        assert pal[n]["mode"] == "kmeans" and pal[n]["cluster_index"] == k
+        assert pal[n]["cluster_lab"] == [int(v) for v in want["centers"][k]]
+        assert pal[n]["pixels"] == int(counts[k]) and pal[n]["mask_nonzero"] == int(np.count_nonzero(want["masks"][n]))
+        assert pal[n]["approx_bgr"] == list(O.lab8_to_bgr(want["centers"][k].astype(np.uint8)))
+    # edges_composite.png (03:60-111): white canvas, every layer's edge pixels painted in config order with cfg.colors[i] (the palette
+    # holds "approx_bgr", never "bgr", so the reference always takes its fallback colour, 03:83-91); later layers overwrite earlier ones
+    comp = np.full(img.shape, 255, np.uint8)
+    colors = [(0, 0, 0), (255, 0, 0), (0, 255, 0), (0, 0, 255)]            # Config.colors defaults (config.py:21), BGR
+    for i, n in enumerate(layer_names(K)):
+        comp[want["edges"][n] > 0] = colors[i]
+    got = np.array(Image.open(out / "edges_composite.png").convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(got, comp)
 
 
 def test_missing_input_aborts_with_nonzero_exit(tmp_path):

@@ -33,8 +33,9 @@ def _worker(rank, world, port, q):
         dev = Device(0)
 
         def snapshot(layers):
+            """{global layer id: artefacts}; `layers` lists the global ids in the order of the device's (local) layer indices"""
             R = S.r_insert12(cfg)
-            return {g: (dev.get_polys_flat(L.SLOT_LINES_CROSS, g), dev.get_taps(L.TAPS_CROSS, g), dev.plot_order(g, R).copy()) for g in layers}
+            return {g: (dev.get_polys_flat(L.SLOT_LINES_CROSS, i), dev.get_taps(L.TAPS_CROSS, i), dev.plot_order(i, R).copy()) for i, g in enumerate(layers)}
 
         dev.set_image(img)
         P.run_path_sharded(dev, cfg, H, W, 0, 1)                       # the whole path on this process

@@ -89,3 +89,28 @@ def test_virtual_draw_08(i):
         segs = O.virtual_draw08(p, mask)
         assert same_polys(segs, unflat(G, f"vdraw{i}_out{j}")), (i, j)
     assert np.array_equal(np.packbits(mask > 0), G[f"vdraw{i}_mask"])
+
+
+def test_lab8_to_bgr_round_trip():
+    """a6 (02:58-61): the palette's approx_bgr.  Pinned to the oracle's FORWARD 8-bit Lab tables: converting the result back gives
+    the same Lab triple within 2 LSB for in-gamut colours (greys, tinted greys, saturated primaries), exact for black and white."""
+    rng = np.random.default_rng(3)
+    cols = [np.array([v, v, v]) for v in range(0, 256, 5)] + [rng.integers(0, 256, 3) for _ in range(300)]
+    for bgr in cols:
+        lab = O.bgr2lab(np.asarray(bgr, np.uint8).reshape(1, 1, 3)).reshape(3)
+        back = O.lab8_to_bgr(lab)
+        lab2 = O.bgr2lab(np.asarray(back, np.uint8).reshape(1, 1, 3)).reshape(3)
+        assert np.abs(lab2.astype(int) - lab.astype(int)).max() <= 2, (bgr, lab, back, lab2)
+    assert O.lab8_to_bgr(O.bgr2lab(np.zeros((1, 1, 3), np.uint8)).reshape(3)) == (0, 0, 0)
+    assert O.lab8_to_bgr(O.bgr2lab(np.full((1, 1, 3), 255, np.uint8)).reshape(3)) == (255, 255, 255)
+
+
+def test_product_lab8_to_bgr_equals_oracle():
+    import importlib.util, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "omnirevolve-image-processor_amd"))
+    from orip.stages import lab8_to_bgr
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        lab = rng.integers(0, 256, 3).astype(np.uint8)
+        assert lab8_to_bgr(lab) == O.lab8_to_bgr(lab), lab
