@@ -59,7 +59,7 @@ struct WalkArgs {
     const unsigned long long* pts_off; const unsigned* path_off;   // exclusive scans over winfo (len_kept, kept)
     unsigned long long layer_pts_base[ORIP_MAX_LAYERS]; unsigned layer_path_base[ORIP_MAX_LAYERS];
     int32_t* pts[ORIP_MAX_LAYERS]; int64_t* off[ORIP_MAX_LAYERS];
-    unsigned long long* dbg;           // optional counters, 8 per component
+    unsigned long long* dbg;           // optional counters, 16 per component
 };
 
 #ifndef ORIP_WALK_LEAD
@@ -69,119 +69,231 @@ struct WalkArgs {
 #define ORIP_WALK_BATCH 4u      // first look-up of a no-fresh run after this many pending states; the batch then doubles (at most one state per lane)
 #endif
 namespace walk_detail {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ORIP_WALK_PROF)
+#define WPROF_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#else
+#define WPROF_NOW() 0ull
+#endif
+#define WPROF_ADD(acc, t0) do { (acc) += WPROF_NOW() - (t0); } while (0)
+
+// Why the stepping of a leftover walk comes back to its caller (Wave::run)
+enum { EV_DEAD = 1,      // the cursor has no neighbour to go to (or, on the GPU, stands on a flagged window cell: ring / start pixel)
+       EV_PEND = 2,      // a fresh step lies ahead while no-fresh states are pending: look them up first
+       EV_LIMIT = 3,     // `steps` reached `limit` (code window full, guard, log room)
+       EV_HOME = 4,      // back on the start pixel (04:196)
+       EV_BATCH = 5 };   // nb reached nbatch
+struct Hot { unsigned steps, limit, nb, nbatch, allow; };   // allow = NEIGH8 directions open to the next step: 0xff without the way back
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WT 64
 #define WTP (WT + 4)
-// One wavefront walks one component.  The walk itself is a strictly serial chain executed by a wave that has its SIMD to itself,
-// so its speed is the number of instructions per step: the cursor is kept as global coordinates + linear index + offset inside a
-// 64x64 LDS window of the state bytes, the eight neighbours are read by lanes 0..7 through a per-lane constant offset, and the
-// previous pixel is excluded by its lane number (NEIGH8 is point-symmetric: the way back from a step in direction k is 7 - k).
+// window bytes (LDS), a re-coding of the state bytes that makes the two tests of a step one signed compare each:
+//   bit7 foreground, bit6 visited            ->  "foreground" = byte < 0, "foreground and not visited" = byte < -64
+//   bit5 ring cell of the window, bit4 start pixel of the walk (flags; the cursor may not probe from / walk through such a cell)
+//   bit1 junction, bit0 endpoint
+#define WB_FG 0x80
+#define WB_VIS 0x40
+#define WB_RING 0x20
+#define WB_HOME 0x10
+#define WB_JUN 2
+#define WB_END 1
+// One wavefront walks one component.  The walk is a strictly serial chain executed by a wave that has its SIMD to itself.  Measured on
+// MI355X for such a wave (tools/walkbench): every instruction ~4.5 cycles, a not-taken branch +10, a taken one 20, a scalar instruction
+// that consumes an SGPR written by a vector instruction (ballot, v_readlane) +16..20, an LDS read 44.  r01's compiled loop spent ~830
+// cycles per step (~95 instructions, 15 branches).  The stepping loop of the leftover walks is therefore ONE hand-written asm
+// statement (Wave::run, ~39 instructions, 4 not-taken branches per step, ~300 cycles in the same benchmark):
+//   * the cursor is an LDS offset `li` plus the global linear index `pl`, both advanced by per-lane constants fetched with v_readlane;
+//   * lanes 0..7 read the eight neighbours from a 64x64 LDS window; the read of the NEXT probe is issued as soon as the step is
+//     decided (two copies of the loop body with the registers swapped), so its latency hides behind the bookkeeping of this step;
+//   * lane 8 reads the cursor cell itself with another compare threshold: bit 8 of the second ballot says whether the cell carries a
+//     flag (window ring -> the window must be re-placed; start pixel -> the walk is home), folded into the "no neighbour" exit;
+//   * the visited mark is written back by the lane that read the neighbour (every lane rewrites its byte, lane k with the bit set):
+//     no exec-mask changes; every step leaves ONE record ((pl << 3 | k) << 2 | fresh << 1) in lane (step & 63) of a VGPR
+//     (v_writelane): direction codes, visited marks for the state plane and pending no-fresh states are all decoded from it by the
+//     64 lanes in parallel when the loop is left (at least every 64 steps).
 struct Wave {
     int lane;
     u8* tile;                   // [WT][WTP]
+    unsigned lds_base;          // LDS byte address of tile[0]
     int tx0, ty0; bool have; unsigned nload;
-    int px, py; unsigned pl;    // cursor
-    int li;                     // cursor offset inside the window (set by probe)
-    int noff;                   // this lane's neighbour offset inside the window (lanes 0..7)
-    u8 myv;                     // state byte of this lane's neighbour (after probe)
+    unsigned pl;                // cursor: global linear index
+    int li;                     // cursor offset inside the window (valid while !reload)
+    bool reload;                // the window has to be (re)placed before the next probe
+    int lastk;                  // direction of the last step (8: none): a reloaded window leads that way
+    int noff, noffa, dplv;      // this lane's neighbour offset: inside the window, the same + lds_base, in the image (lanes 0..7; lanes >= 8: the cursor cell)
+    unsigned sel;               // WB_VIS << lane for lanes 0..7, 0 for the others: (sel >> k) & WB_VIS is the mark in lane k only
+    int thr;                    // compare threshold of "foreground and not visited": -64; lane 8 (cursor cell): -48 = "carries no flag"
+    int va, v;                  // window address this lane read in the last probe (relative to tile) and the byte it got (sign-extended)
+    int rec;                    // lane j: record of the latest step t with (t & 63) == j
+    unsigned home;              // start pixel of the leftover walk in progress (its window cell carries WB_HOME), ~0u: none
+    unsigned codes_done, marks_done;    // steps of the walk whose code / visited mark has left the wave
     u8* st; int W, H;
-    // Global stores inside the step loop would make every later s_waitcnt vmcnt(0) of the loop wait for a full store round trip, so
-    // the loop only writes LDS: visited marks go to the window at once and to `mlist` (flushed to memory, all lanes, before anything
-    // reads the state bytes from memory again); direction codes go to `sbuf` and reach the step log 64 at a time.
-    unsigned* mlist; int nm;    // pending marks: (linear index << 4) | state byte
-    int lead_x = 0, lead_y = 0; // window placement ahead of the cursor (ORIP_WALK_LEAD px in the direction of the last step)
-    u8* sbuf; unsigned codes_done;
-    __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0), px(0), py(0), pl(0), li(0), myv(0), st(nullptr), W(0), H(0) {
+    unsigned long long t_tile = 0;
+    __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0), pl(0), li(0), reload(true), lastk(8), noff(0), noffa(0), dplv(0), sel(0), thr(-64),
+                        va(0), v(0), rec(0), home(~0u), codes_done(0), marks_done(0), st(nullptr), W(0), H(0) {
         __shared__ u8 lds_tile[WT * WTP];
-        __shared__ unsigned lds_marks[64];
-        __shared__ u8 lds_codes[64];
-        tile = lds_tile; mlist = lds_marks; nm = 0; sbuf = lds_codes; codes_done = 0;
-        const int k = lane & 7;
-        noff = ((int)((0xA940u >> (2 * k)) & 3u) - 1) * WTP + (int)((0x9224u >> (2 * k)) & 3u) - 1;
+        tile = lds_tile; lds_base = (unsigned)(uintptr_t)lds_tile;
     }
-    __device__ void init(u8* st_, int W_, int H_) { st = st_; W = W_; H = H_; }
+    __device__ void init(u8* st_, int W_, int H_) {
+        st = st_; W = W_; H = H_;
+        if (lane < 8) {
+            const int dx = (int)((0x9224u >> (2 * lane)) & 3u) - 1, dy = (int)((0xA940u >> (2 * lane)) & 3u) - 1;
+            noff = dy * WTP + dx; dplv = dy * W + dx; sel = (unsigned)WB_VIS << lane;
+        }
+        if (lane == 8) thr = -48;
+        noffa = noff + (int)lds_base;
+    }
     __device__ bool leader() const { return lane == 0; }
     __device__ unsigned l0() const { return (unsigned)lane; }
     __device__ unsigned nl() const { return 64u; }
     __device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0); }
     // lane 0 loads, everybody gets the value
-    __device__ unsigned ld0(const unsigned* p) const { unsigned v = 0; if (lane == 0) v = *p; return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ unsigned ld0(const unsigned* p) const { unsigned x = 0; if (lane == 0) x = *p; return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
     // one 16-byte record (state, cont, end, begin) with a single load
     __device__ void ld0_rec(const unsigned* p, unsigned& cont, unsigned& en, unsigned& begin) const {
-        uint4 v = make_uint4(0, 0, 0, 0); if (lane == 0) v = *reinterpret_cast<const uint4*>(p);
-        cont = (unsigned)__builtin_amdgcn_readfirstlane((int)v.y); en = (unsigned)__builtin_amdgcn_readfirstlane((int)v.z); begin = (unsigned)__builtin_amdgcn_readfirstlane((int)v.w);
+        uint4 x = make_uint4(0, 0, 0, 0); if (lane == 0) x = *reinterpret_cast<const uint4*>(p);
+        cont = (unsigned)__builtin_amdgcn_readfirstlane((int)x.y); en = (unsigned)__builtin_amdgcn_readfirstlane((int)x.z); begin = (unsigned)__builtin_amdgcn_readfirstlane((int)x.w);
     }
-    __device__ void flush_marks() {
-        if (nm) { if (lane < nm) { const unsigned e = mlist[lane]; st[e >> 4] = (u8)(e & 15u); } nm = 0; }
+    // The visited bits of the state plane are set with atomic ORs (no result, nothing to wait for) and every read of the plane by this
+    // wave goes to L2 (agent-scope relaxed loads): an atomic executes in L2 and does not refresh a line the CU's L1 may still hold.
+    __device__ u8 ld_state(unsigned lin) const { return __hip_atomic_load(st + lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ void or_visited(unsigned lin) const {
+        const uintptr_t a = (uintptr_t)(st + lin);
+        atomicOr(reinterpret_cast<unsigned*>(a & ~(uintptr_t)3), (unsigned)ST_VIS << (8u * (unsigned)(a & 3)));
+    }
+    // step index of the record this lane holds (the latest step t < steps with (t & 63) == lane); >= steps: none
+    __device__ unsigned my_step(unsigned steps) const { return steps - 1u - ((steps - 1u - (unsigned)lane) & 63u); }
+    // visited marks of the steps [marks_done, steps) -> state plane
+    __device__ void flush_marks(unsigned steps) {
+        if (steps > marks_done) {
+            const unsigned t = my_step(steps);
+            if (t < steps && t >= marks_done && (rec & 2)) or_visited((unsigned)rec >> 5);
+            marks_done = steps;
+        }
     }
     // marks of the walk so far are in memory (before the state bytes are read from memory: next scan, next window)
-    __device__ void sync_marks() { flush_marks(); fence(); }
-    __device__ void begin_codes() { codes_done = 0; }
-    __device__ void put_code(u8* slog, unsigned room, unsigned idx, int k) {
-        if (lane == 0) sbuf[idx & 63u] = (u8)k;
-        if ((idx & 63u) == 63u) { const unsigned p = (idx & ~63u) + (unsigned)lane; if (p < room) slog[p] = sbuf[lane]; codes_done = idx + 1u; }
+    __device__ void sync_marks(unsigned steps) { flush_marks(steps); fence(); }
+    __device__ void begin_walk(unsigned home_) { codes_done = 0; marks_done = 0; home = home_; }
+    // direction codes of the steps [codes_done, steps) -> step log (called when a window of 64 steps is full, and at the end of a walk)
+    __device__ void flush_codes(u8* slog, unsigned room, unsigned steps) {
+        if (steps > codes_done) {
+            const unsigned t = my_step(steps);
+            if (t < steps && t >= codes_done && t < room) slog[t] = (u8)(((unsigned)rec >> 2) & 7u);
+            codes_done = steps;
+        }
+        flush_marks(steps);
     }
-    __device__ void finish_codes(u8* slog, unsigned room, unsigned steps) {
-        if (steps > codes_done) { const unsigned p = codes_done + (unsigned)lane; if (p < steps && p < room) slog[p] = sbuf[p & 63u]; }
-    }
-    __device__ void load_tile(int cx, int cy) {
-        flush_marks();
+    // state ((pl << 3) | k) of the step with index `first + lane` (one of the last 64 steps)
+    __device__ unsigned pending(unsigned first) const { return (unsigned)__shfl(rec, (int)((first + (unsigned)lane) & 63u), 64) >> 2; }
+    __device__ void load_tile(int cx, int cy, unsigned steps) {
+        const unsigned long long t_0 = WPROF_NOW();
+        flush_marks(steps);
         fence();                                                      // earlier marks have reached memory
+        const int lead_x = lastk < 8 ? ((int)((0x9224u >> (2 * lastk)) & 3u) - 1) * ORIP_WALK_LEAD : 0;
+        const int lead_y = lastk < 8 ? ((int)((0xA940u >> (2 * lastk)) & 3u) - 1) * ORIP_WALK_LEAD : 0;
         tx0 = ((cx - WT / 2 + lead_x) >> 2) << 2; ty0 = cy - WT / 2 + lead_y;          // 4-byte aligned columns; the window leads in the direction of the last step
         const int y = ty0 + lane;
         u8* row = tile + lane * WTP;
-        if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0u; }
+        const uint32_t ring_row = (lane == 0 || lane == WT - 1) ? 0x20202020u : 0u;     // first and last row: every cell
+        auto recode = [](uint32_t w) -> uint32_t { return ((w & 0x01010101u) << 7) | ((w & 0x02020202u) << 5) | ((w >> 2) & 0x03030303u); };
+        if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0x20202020u; }   // outside the image: not foreground; the flag is harmless
         else if ((W & 3) == 0 && tx0 >= 0 && tx0 + WT <= W) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (size_t)y * W + tx0);
+            uint32_t w[WT / 4];
 #pragma unroll
-            for (int j = 0; j < WT / 4; j++) *reinterpret_cast<uint32_t*>(row + 4 * j) = src[j];
+            for (int j = 0; j < WT / 4; j++) w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < WT / 4; j++) {
+                uint32_t x = recode(w[j]) | ring_row;
+                if (j == 0) x |= 0x20u;
+                if (j == WT / 4 - 1) x |= 0x20000000u;
+                *reinterpret_cast<uint32_t*>(row + 4 * j) = x;
+            }
         } else {
-            for (int j = 0; j < WT; j++) { int x = tx0 + j; row[j] = (x >= 0 && x < W) ? st[(size_t)y * W + x] : (u8)0; }
+            for (int j = 0; j < WT; j++) {
+                int x = tx0 + j; u8 g = (x >= 0 && x < W) ? ld_state((unsigned)((size_t)y * W + x)) : (u8)0;
+                u8 bte = (u8)recode(g);
+                if (ring_row || j == 0 || j == WT - 1) bte |= WB_RING;
+                row[j] = bte;
+            }
         }
         have = true; nload++;
         fence();
-    }
-    __device__ void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; lead_x = lead_y = 0; }
-    // marks the cursor pixel itself (start of a walk): global memory and, when inside, the window
-    __device__ void mark_cursor(u8 v) {
-        if (lane == 0) {
-            st[pl] = (u8)(v | ST_VIS);
-            const int lx = px - tx0, ly = py - ty0;
-            if (have && (unsigned)lx < (unsigned)WT && (unsigned)ly < (unsigned)WT) tile[ly * WTP + lx] = (u8)(v | ST_VIS);
+        if (home != ~0u && steps > 0 && lane == 0) {                  // the start pixel of the walk inside the new window
+            const int hx = (int)(home % (unsigned)W) - tx0, hy = (int)(home / (unsigned)W) - ty0;
+            if ((unsigned)hx < (unsigned)WT && (unsigned)hy < (unsigned)WT) tile[hy * WTP + hx] |= WB_HOME;
         }
+        fence();
+        WPROF_ADD(t_tile, t_0);
     }
-    // neighbours of the cursor; kopp = NEIGH8 index of the previous pixel (8: none).  Masks over NEIGH8 indices.
-    __device__ void probe(int kopp, unsigned& m_any, unsigned& m_unvis) {
+    __device__ void set_cursor(unsigned lin) { pl = lin; reload = true; lastk = 8; }
+    // window offset of the cursor; reloads the window unless the cursor is strictly inside the current one
+    __device__ void place(unsigned steps) {
+        const int px = (int)(pl % (unsigned)W), py = (int)(pl / (unsigned)W);
         int lx = px - tx0, ly = py - ty0;
-        if (!have || (unsigned)(lx - 1) > (unsigned)(WT - 3) || (unsigned)(ly - 1) > (unsigned)(WT - 3)) { load_tile(px, py); lx = px - tx0; ly = py - ty0; }
-        li = ly * WTP + lx;
-        unsigned v = 0;
-        if (lane < 8) v = tile[li + noff];                            // out-of-image cells of the window hold 0; lanes >= 8 contribute nothing
-        myv = (u8)v;
-        // two ballots on single-bit tests, the rest on the scalar unit
-        const unsigned m_fg = (unsigned)__ballot((v & ST_FG) != 0), m_vis = (unsigned)__ballot((v & ST_VIS) != 0);
-        m_any = m_fg & ~(1u << kopp);                                  // kopp == 8 clears nothing
-        m_unvis = m_any & ~m_vis;
+        if (!have || (unsigned)(lx - 1) > (unsigned)(WT - 3) || (unsigned)(ly - 1) > (unsigned)(WT - 3)) { load_tile(px, py, steps); lx = px - tx0; ly = py - ty0; }
+        li = ly * WTP + lx; reload = false;
     }
-    __device__ u8 value_of(int k) const { return (u8)__builtin_amdgcn_readlane((int)myv, k); }
-    // moves the cursor to neighbour k (after probe); mark: the neighbour becomes visited (it lies inside the window: the cursor is interior)
-    __device__ void step(int k, bool mark) {
-        const int dx = (int)((0x9224u >> (2 * k)) & 3u) - 1, dy = (int)((0xA940u >> (2 * k)) & 3u) - 1;
-        px += dx; py += dy; pl = (unsigned)((int)pl + dy * W + dx);
-        lead_x = dx * ORIP_WALK_LEAD; lead_y = dy * ORIP_WALK_LEAD;
-        if (mark) {
-            const u8 v = (u8)(value_of(k) | ST_VIS);
-            if (lane == 0) { tile[li + dy * WTP + dx] = v; mlist[nm] = (pl << 4) | v; }
-            if (++nm == 64) flush_marks();
+    // marks the cursor pixel itself (start of a walk): state plane and, when inside, the window.  gv: its state byte (global coding)
+    __device__ void mark_cursor(u8 gv) {
+        if (lane == 0) {
+            st[pl] = (u8)(gv | ST_VIS);
+            if (have) {
+                const int lx = (int)(pl % (unsigned)W) - tx0, ly = (int)(pl / (unsigned)W) - ty0;
+                if ((unsigned)lx < (unsigned)WT && (unsigned)ly < (unsigned)WT) tile[ly * WTP + lx] |= WB_VIS;
+            }
         }
+        fence();
     }
-    __device__ unsigned bcast(unsigned v, int src) const { return (unsigned)__shfl((int)v, src, 64); }
+    // the walk has left its start pixel: from now on stepping onto it ends the walk (the cell lies next to the cursor, inside the window)
+    __device__ void flag_home() {
+        if (lane == 0 && home != ~0u) {
+            const int hx = (int)(home % (unsigned)W) - tx0, hy = (int)(home / (unsigned)W) - ty0;
+            if (have && (unsigned)hx < (unsigned)WT && (unsigned)hy < (unsigned)WT) tile[hy * WTP + hx] |= WB_HOME;
+        }
+        fence();
+    }
+    // neighbours of the cursor; allow: NEIGH8 directions that may be taken (all but the way back).  Masks over NEIGH8 indices.
+    __device__ void probe(unsigned allow, unsigned steps, unsigned& m_any, unsigned& m_unvis) {
+        if (reload) place(steps);
+        va = li + noff;
+        v = (int)(signed char)tile[va];
+        const unsigned m_fg = (unsigned)__builtin_amdgcn_ballot_w64(v < 0), m_un = (unsigned)__builtin_amdgcn_ballot_w64(v < -64);
+        m_any = m_fg & allow & 0xffu;                                  // lanes >= 8 (reading the cursor cell) never count
+        m_unvis = m_any & m_un;
+    }
+    // moves the cursor to neighbour k (after probe), records the step and returns the neighbour's state byte (global coding); fresh: it becomes visited
+    __device__ u8 step(int k, bool fresh, unsigned steps) {
+        const int vk = __builtin_amdgcn_readlane(v, k);
+        li += __builtin_amdgcn_readlane(noff, k);
+        pl = (unsigned)((int)pl + __builtin_amdgcn_readlane(dplv, k));
+        lastk = k;
+        const int r = (int)((((pl << 3) | (unsigned)k) << 2) | (fresh ? 2u : 0u));
+        rec = lane == (int)(steps & 63u) ? r : rec;
+        if (fresh) tile[va] = (u8)(v | (int)((sel >> k) & WB_VIS));   // every lane writes its byte back, lane k with the visited bit: no exec juggling
+        reload = (vk & WB_RING) != 0;
+        return (u8)(ST_FG | ((vk & WB_VIS) || fresh ? ST_VIS : 0) | ((vk & WB_END) ? ST_END : 0) | ((vk & WB_JUN) ? ST_JUN : 0));
+    }
+    // after EV_DEAD: 2 = the cursor stands on the start pixel of the walk, 1 = it stood on the window ring (window re-placed), 0 = neither
+    __device__ int resume_flagged(unsigned steps) {
+        const u8 cell = tile[li];
+        if (cell & WB_HOME) {
+            if (pl == home) return 2;
+            if (lane == 0) tile[li] = (u8)(cell & ~WB_HOME);          // the start pixel of an earlier walk: the flag is stale
+            fence();
+            if (!(cell & WB_RING)) return 1;
+        }
+        if (cell & WB_RING) { reload = true; place(steps); return 1; }
+        return 0;
+    }
+    __device__ void log_code(u8*, unsigned, unsigned, int) {}      // the record of the step carries its code
+    __device__ unsigned bcast(unsigned x, int src) const { return (unsigned)__shfl((int)x, src, 64); }
     __device__ int first(bool pred) const { unsigned long long m = __ballot(pred); return m ? __ffsll((long long)m) - 1 : -1; }
     // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
     __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q += 64) {
             unsigned qq = q + lane; bool ok = false;
-            if (qq < e) { u8 v = st[lin[qq]]; ok = ((v & need) == need) && !(v & ST_VIS); }
+            if (qq < e) { u8 x = ld_state(lin[qq]); ok = ((x & need) == need) && !(x & ST_VIS); }
             unsigned long long m = __ballot(ok);
             if (m) return q + (unsigned)(__ffsll((long long)m) - 1);
         }
@@ -192,11 +304,113 @@ struct Wave {
         for (int o = 1; o < 64; o <<= 1) { int ax = __shfl_up(dx, o, 64), ay = __shfl_up(dy, o, 64); if (lane >= o) { dx += ax; dy += ay; } }
         ox = dx; oy = dy; tx = __shfl(dx, 63, 64); ty = __shfl(dy, 63, 64);
     }
+    // ---- the stepping loop of a leftover walk (04:176-199) until something needs the caller: see EV_*.
+    // In: cursor placed (li valid, not on a flagged cell unless the caller wants EV_DEAD at once), h.steps < h.limit <= next multiple of 64.
+    // Per step: probe; m = unvisited neighbours else any neighbour but the way back; none -> EV_DEAD; fresh with pending states -> EV_PEND;
+    // step to the first one in NEIGH8 order; record; mark it when fresh, else count it as pending; steps == limit -> EV_LIMIT;
+    // nb == nbatch -> EV_BATCH.  A flagged cursor cell (ring, start pixel) makes the next probe come back empty -> EV_DEAD.
+    __device__ int run(Hot& h, u8*, unsigned) {
+        if (h.steps == 0) {
+            // the first step of a walk goes through probe() / step(): its start cell only gets the WB_HOME flag once the cursor has left it
+            unsigned f_any, f_un;
+            probe(h.allow, 0u, f_any, f_un);
+            const unsigned fm = f_un ? f_un : f_any;
+            if (!fm) return EV_DEAD;
+            const int fk = __builtin_ctz(fm);
+            step(fk, f_un != 0, 0u);
+            h.steps = 1; h.allow = 0xffu & ~(0x80u >> fk); h.nb = f_un ? 0u : 1u;
+            flag_home();
+            if (h.steps >= h.limit) return EV_LIMIT;
+            if (h.nb >= h.nbatch) return EV_BATCH;
+            // (a first step onto the window ring: the loop below comes back with EV_DEAD at once and the caller re-places the window)
+        }
+        int ev;
+        int r_va, r_v, r_vb, r_w, r_t2;
+        unsigned m_any, m_un, m, frmask, fr2, fr40, r, tmp, k, m0save;
+        int s_li = __builtin_amdgcn_readfirstlane(li);
+        unsigned s_pl = (unsigned)__builtin_amdgcn_readfirstlane((int)pl), s_allow = (unsigned)__builtin_amdgcn_readfirstlane((int)h.allow);
+        unsigned s_steps = (unsigned)__builtin_amdgcn_readfirstlane((int)h.steps), s_nb = (unsigned)__builtin_amdgcn_readfirstlane((int)h.nb);
+        const unsigned s_limit = (unsigned)__builtin_amdgcn_readfirstlane((int)h.limit), s_nbatch = (unsigned)__builtin_amdgcn_readfirstlane((int)h.nbatch);
+#define ORIP_WALK_HALF(TAG, VA, V, VB, VW)                                                                            \
+        "L_" TAG "%=:\n\t"                                                                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "v_cmp_gt_i32 vcc, 0, %[" V "]\n\t"                         /* foreground */                                  \
+        "s_and_b32 %[m_any], vcc_lo, %[allow]\n\t"                                                                    \
+        "v_cmp_gt_i32 vcc, %[thr], %[" V "]\n\t"                    /* lanes 0..7: foreground, not visited; lane 8: cursor cell unflagged */ \
+        "s_bitcmp1_b32 vcc_lo, 8\n\t"                                                                                 \
+        "s_cselect_b32 %[m_any], %[m_any], 0\n\t"                                                                     \
+        "s_and_b32 %[m_un], %[m_any], vcc_lo\n\t"                                                                     \
+        "s_cselect_b32 %[m], %[m_un], %[m_any]\n\t"                                                                   \
+        "s_cselect_b32 %[frmask], -1, 0\n\t"                                                                          \
+        "s_cmp_eq_u32 %[m], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 L_dead%=\n\t"                                                                                 \
+        "s_and_b32 %[tmp], %[frmask], %[nb]\n\t"                                                                      \
+        "s_cbranch_scc1 L_pend%=\n\t"                                                                                 \
+        "s_ff1_i32_b32 %[k], %[m]\n\t"                                                                                \
+        "s_and_b32 %[fr40], %[frmask], 64\n\t"                                                                        \
+        "v_readlane_b32 %[tmp], %[noff], %[k]\n\t"                                                                    \
+        "v_lshrrev_b32 %[t2], %[k], %[sel]\n\t"                                                                       \
+        "s_add_i32 %[li], %[li], %[tmp]\n\t"                                                                          \
+        "v_and_or_b32 %[t2], %[t2], %[fr40], %[" V "]\n\t"                                                            \
+        "v_add_u32 %[" VB "], %[li], %[noffa]\n\t"                                                                    \
+        "ds_write_b8 %[" VA "], %[t2]\n\t"                                                                            \
+        "ds_read_i8 %[" VW "], %[" VB "]\n\t"                                                                         \
+        "v_readlane_b32 %[tmp], %[dplv], %[k]\n\t"                                                                    \
+        "s_and_b32 %[fr2], %[frmask], 2\n\t"                                                                          \
+        "s_add_i32 %[pl], %[pl], %[tmp]\n\t"                                                                          \
+        "s_lshl3_add_u32 %[r], %[pl], %[k]\n\t"                                                                       \
+        "s_lshl2_add_u32 %[r], %[r], %[fr2]\n\t"                                                                      \
+        "v_writelane_b32 %[rec], %[r], m0\n\t"                                                                        \
+        "s_add_i32 %[nb], %[nb], 1\n\t"                                                                               \
+        "s_andn2_b32 %[nb], %[nb], %[frmask]\n\t"                                                                     \
+        "s_lshr_b32 %[tmp], 0x80, %[k]\n\t"                                                                           \
+        "s_andn2_b32 %[allow], 0xff, %[tmp]\n\t"                                                                      \
+        "s_add_i32 %[steps], %[steps], 1\n\t"                                                                         \
+        "s_add_i32 m0, m0, 1\n\t"                                                                                     \
+        "s_cmp_ge_u32 %[steps], %[limit]\n\t"                                                                         \
+        "s_cbranch_scc1 L_limit%=\n\t"                                                                                \
+        "s_cmp_ge_u32 %[nb], %[nbatch]\n\t"                                                                           \
+        "s_cbranch_scc1 L_batch%=\n\t"
+        asm volatile(
+            "s_mov_b32 %[m0save], m0\n\t"
+            "s_and_b32 m0, %[steps], 63\n\t"
+            "v_add_u32 %[va], %[li], %[noffa]\n\t"
+            "ds_read_i8 %[v], %[va]\n\t"
+            ORIP_WALK_HALF("A", "va", "v", "vb", "w")
+            ORIP_WALK_HALF("B", "vb", "w", "va", "v")
+            "s_branch L_A%=\n\t"
+            "L_batch%=:\n\t"
+            "s_mov_b32 %[ev], 5\n\t"
+            "s_branch L_out%=\n\t"
+            "L_dead%=:\n\t"
+            "s_mov_b32 %[ev], 1\n\t"
+            "s_branch L_out%=\n\t"
+            "L_pend%=:\n\t"
+            "s_mov_b32 %[ev], 2\n\t"
+            "s_branch L_out%=\n\t"
+            "L_limit%=:\n\t"
+            "s_mov_b32 %[ev], 3\n\t"
+            "L_out%=:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b32 m0, %[m0save]\n\t"
+            : [ev] "=&s"(ev), [li] "+s"(s_li), [pl] "+s"(s_pl), [allow] "+s"(s_allow), [steps] "+s"(s_steps), [nb] "+s"(s_nb),
+              [rec] "+v"(rec), [va] "=&v"(r_va), [v] "=&v"(r_v), [vb] "=&v"(r_vb), [w] "=&v"(r_w), [t2] "=&v"(r_t2),
+              [m_any] "=&s"(m_any), [m_un] "=&s"(m_un), [m] "=&s"(m), [frmask] "=&s"(frmask), [fr2] "=&s"(fr2), [fr40] "=&s"(fr40), [r] "=&s"(r), [tmp] "=&s"(tmp),
+              [k] "=&s"(k), [m0save] "=&s"(m0save)
+            : [limit] "s"(s_limit), [nbatch] "s"(s_nbatch), [noff] "v"(noff), [noffa] "v"(noffa), [dplv] "v"(dplv), [sel] "v"(sel), [thr] "v"(thr)
+            : "vcc", "scc", "memory");
+#undef ORIP_WALK_HALF
+        li = s_li; pl = s_pl; h.allow = s_allow; h.steps = s_steps; h.nb = s_nb;
+        const unsigned back = ~s_allow & 0xffu;                       // bit kopp = 7 - k of the last step
+        lastk = back ? 7 - (int)__builtin_ctz(back) : 8;
+        return ev;
+    }
 };
 #else
 struct Wave {
-    u8 nv[8]; unsigned nload = 0;
-    int px = 0, py = 0; unsigned pl = 0;
+    u8 nv[8]; unsigned nload = 0; unsigned long long t_tile = 0;
+    unsigned pl = 0, home = ~0u;
+    unsigned pend_state = 0;
     u8* st = nullptr; int W = 0, H = 0;
     void init(u8* st_, int W_, int H_) { st = st_; W = W_; H = H_; }
     bool leader() const { return true; }
@@ -205,27 +419,52 @@ struct Wave {
     void fence() const {}
     unsigned ld0(const unsigned* p) const { return *p; }
     void ld0_rec(const unsigned* p, unsigned& cont, unsigned& en, unsigned& begin) const { cont = p[1]; en = p[2]; begin = p[3]; }
-    void set_cursor(int x, int y) { px = x; py = y; pl = (unsigned)y * (unsigned)W + (unsigned)x; }
+    u8 ld_state(unsigned lin) const { return st[lin]; }
+    void set_cursor(unsigned lin) { pl = lin; }
     void mark_cursor(u8 v) { st[pl] = (u8)(v | ST_VIS); }
-    void sync_marks() {}
-    void begin_codes() {}
-    void put_code(u8* slog, unsigned, unsigned idx, int k) { slog[idx] = (u8)k; }
-    void finish_codes(u8*, unsigned, unsigned) {}
-    void probe(int kopp, unsigned& m_any, unsigned& m_unvis) {
+    void flag_home() {}
+    void sync_marks(unsigned) {}
+    void begin_walk(unsigned home_) { home = home_; }
+    void flush_codes(u8*, unsigned, unsigned) {}
+    unsigned pending(unsigned) const { return pend_state; }
+    int resume_flagged(unsigned) { return 0; }
+    void log_code(u8* slog, unsigned room, unsigned idx, int k) { if (idx < room) slog[idx] = (u8)k; }
+    void probe(unsigned allow, unsigned, unsigned& m_any, unsigned& m_unvis) {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        const int px = (int)(pl % (unsigned)W), py = (int)(pl / (unsigned)W);
         m_any = m_unvis = 0;
         for (int k = 0; k < 8; k++) {
             int xx = px + dxs[k], yy = py + dys[k]; nv[k] = 0;
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
             u8 v = st[(size_t)yy * W + xx]; nv[k] = v;
-            if ((v & ST_FG) && k != kopp) { m_any |= 1u << k; if (!(v & ST_VIS)) m_unvis |= 1u << k; }
+            if ((v & ST_FG) && ((allow >> k) & 1u)) { m_any |= 1u << k; if (!(v & ST_VIS)) m_unvis |= 1u << k; }
         }
     }
-    u8 value_of(int k) const { return nv[k]; }
-    void step(int k, bool mark) {
+    u8 step(int k, bool mark, unsigned) {
         const int dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-        px += dxs[k]; py += dys[k]; pl = (unsigned)py * (unsigned)W + (unsigned)px;
+        pl = (unsigned)((int)pl + dys[k] * W + dxs[k]);
         if (mark) st[pl] = (u8)(nv[k] | ST_VIS);
+        return (u8)(nv[k] | (mark ? ST_VIS : 0));
+    }
+    // the same loop as the GPU's Wave::run, one lane: codes go straight to the step log, one pending state at most (nbatch == 1)
+    int run(Hot& h, u8* slog, unsigned room) {
+        while (true) {
+            unsigned m_any, m_un;
+            probe(h.allow, h.steps, m_any, m_un);
+            const bool fresh = m_un != 0;
+            const unsigned m = fresh ? m_un : m_any;
+            if (!m) return EV_DEAD;
+            if (fresh && h.nb) return EV_PEND;
+            const int k = __builtin_ctz(m);
+            log_code(slog, room, h.steps, k);
+            step(k, fresh, h.steps);
+            h.steps++;
+            h.allow = 0xffu & ~(0x80u >> k);
+            if (!fresh) { pend_state = (pl << 3) | (unsigned)k; h.nb++; }
+            if (pl == home) return EV_HOME;
+            if (h.steps >= h.limit) return EV_LIMIT;
+            if (h.nb >= h.nbatch) return EV_BATCH;
+        }
     }
     unsigned bcast(unsigned v, int) const { return v; }
     int first(bool pred) const { return pred ? 0 : -1; }
@@ -269,68 +508,76 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     unsigned logcur = 0, stepcur = 0;
     bool over = false;
     unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
+    unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
         if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
     };
+    auto tscan = [&](unsigned q0, u8 need) { const unsigned long long t_0 = WPROF_NOW(); const unsigned r = wv.scan(A.lin, q0, e, need); WPROF_ADD(t_scan, t_0); return r; };
     // ---- phase 1: walks from endpoints (04:144-171); >= 2 points to be a path (04:168), >= 5 to survive vectorize_layer (04:224)
     const unsigned long long g1 = (unsigned long long)(total_fg * 2);
-    for (unsigned q = wv.scan(A.lin, b, e, ST_FG | ST_END); q < e; q = wv.scan(A.lin, q + 1, e, ST_FG | ST_END)) {
+    for (unsigned q = tscan(b, ST_FG | ST_END); q < e; q = tscan(q + 1, ST_FG | ST_END)) {
         unsigned s = A.lin[q];
-        wv.set_cursor((int)(s % W), (int)(s / W));
+        wv.set_cursor(s);
         const unsigned sbeg = step_base + stepcur;
         u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
+        wv.begin_walk(~0u);
         wv.mark_cursor(ST_FG | ST_END);
-        wv.begin_codes();
-        unsigned steps = 0; int kopp = 8; d_w1++;
+        unsigned steps = 0, allow = 0xffu; d_w1++;
         while (true) {
             unsigned m_any, m_unvis;
-            wv.probe(kopp, m_any, m_unvis);
+            wv.probe(allow, steps, m_any, m_unvis);
             if (!m_unvis) break;
             const int k = ffs8(m_unvis);
-            const u8 v = wv.value_of(k);
-            if (steps < room) wv.put_code(slog, room, steps, k); else over = true;
+            if (steps >= room) over = true;
+            wv.log_code(slog, room, steps, k);
+            const u8 v = wv.step(k, true, steps);
             steps++;
-            wv.step(k, true);
-            kopp = 7 - k;
+            if ((steps & 63u) == 0) wv.flush_codes(slog, room, steps);
+            allow = 0xffu & ~(0x80u >> k);                        // not the way back: NEIGH8 index 7 - k
             if (v & (ST_JUN | ST_END)) break;
             if ((unsigned long long)steps > g1) break;       // guard (04:163): counts the steps that went on
         }
         stepcur += steps; d_s1 += steps;
-        wv.finish_codes(slog, room, steps);
-        wv.sync_marks();  // marks of this walk are complete before the next scan
+        wv.flush_codes(slog, room, steps);
+        wv.sync_marks(steps);  // marks of this walk are complete before the next scan
         finish(2u * b + (q - b), 1ull + steps, steps, sbeg, 0u, 0u, 0u);
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
-    auto log_pos = [&](unsigned i, unsigned long long R, int& ox, int& oy) {   // position R steps after logged state i
+    auto log_pos = [&](unsigned i, unsigned long long R) -> unsigned {   // pixel (linear index) R steps after logged state i
         unsigned long long f = log_resolve(A.logbuf, wv, i, (unsigned long long)i + R);
-        unsigned l = wv.ld0(&A.logbuf[4ull * f]) >> 3;
-        ox = (int)(l % (unsigned)W); oy = (int)(l / (unsigned)W);
+        return wv.ld0(&A.logbuf[4ull * f]) >> 3;
     };
     // A walk that finds no fresh neighbour is on a trajectory that only depends on its state (pixel, incoming direction), so its
     // states are looked up in / added to the memo.  The memo lives in HBM and a look-up per step would put one full memory latency
-    // on every step of a strictly serial chain; instead the walk runs ahead on the LDS window and parks its no-fresh states in the
-    // lanes (lane j = j-th pending state).  flush() then does what the reference order requires for all of them at once: the first
-    // pending state that is already known (to an older record, to this run, or to an earlier pending state) ends the walk there and
-    // the steps taken after it are dropped; otherwise all of them become provisional entries of this run.
+    // on every step of a strictly serial chain; instead the walk runs ahead on the LDS window (Wave::run) and keeps its no-fresh
+    // states pending (they are the records of its last nb steps).  flush() then does what the reference order requires for all of
+    // them at once: the first pending state that is already known (to an older record, to this run, or to an earlier pending state)
+    // ends the walk there and the steps taken after it are dropped; otherwise all of them become provisional entries of this run.
     const unsigned g2 = fg * 4u;                                  // guard of a leftover walk (04:199)
     const unsigned nbatch0 = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
-    for (unsigned q = wv.scan(A.lin, b, e, ST_FG); q < e && !over; q = wv.scan(A.lin, q + 1, e, ST_FG)) {
+    for (unsigned q = tscan(b, ST_FG); q < e && !over; q = tscan(q + 1, ST_FG)) {
         unsigned s = A.lin[q];
-        const int x0 = (int)(s % W), y0 = (int)(s / W);
-        wv.set_cursor(x0, y0);
+        wv.set_cursor(s);
         const unsigned sbeg = step_base + stepcur;
         u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
-        { u8 sv = st[s]; wv.mark_cursor(sv); }
-        wv.begin_codes();
+        wv.begin_walk(s);
+        { u8 sv = wv.ld_state(s); wv.mark_cursor(sv); }
         d_w2++;
-        unsigned steps = 0;                   // steps taken = own points - 1 = value of the reference's guard counter at its check
+        Hot h; h.steps = 0;                   // steps taken = own points - 1 = value of the reference's guard counter at its check
+        h.limit = 0; h.nb = 0;                // pending no-fresh states: those of the last nb steps
+        h.nbatch = nbatch0;                   // memo hits come early in a run or not for a while: 4, 8, 16, ... pending states per look-up
+        h.allow = 0xffu;
         unsigned long long tail_len = 0; unsigned tail_i1 = 0, tail_R = 0;
         unsigned nofresh = 0;                 // no-fresh states logged since the last fresh pixel: entries [run_begin, run_begin + nofresh)
-        unsigned nb = 0, myS = 0, steps_b = 0;                     // pending states; steps before the first of them
-        unsigned nbatch = nbatch0;                                 // memo hits come early in a run or not for a while: 4, 8, 16, ... pending states per look-up
+        unsigned flush_mark = 0;              // h.steps when the last look-up returned: a later pending state that starts beyond it follows a fresh step
+        unsigned drop = 0;                    // 1: the walk ended on the step of the last pending state (start pixel / guard), which the reference does not look at
         // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow
-        auto flush = [&]() -> int {
-            if (!nb) return 0;
+        auto flush_ = [&]() -> int {
+            const unsigned nb = h.nb - drop;
+            if (!nb) { h.nb = 0; return 0; }
+            const unsigned steps_b = h.steps - h.nb;                  // steps before the first pending state
+            if (steps_b > flush_mark) { nofresh = 0; h.nbatch = nbatch0; }      // a fresh pixel since the last look-up: a new run
+            const unsigned myS = wv.pending(steps_b);                 // lane j: j-th pending state
             const unsigned run_begin = log_base + logcur;
             const unsigned me = wv.l0();
             const bool act = me < nb;
@@ -342,15 +589,15 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             for (unsigned jp = 0; jp + 1 < nb; jp++) { const unsigned sj = wv.bcast(myS, (int)jp); if (act && me > jp && myS == sj) { dup = true; dsrc = jp; } }
             const int js = wv.first(hit_old || dup);
             const unsigned ncommit = js < 0 ? nb : (unsigned)js;
-            if (logcur + nofresh + ncommit > log_cap) { over = true; nb = 0; return 2; }
+            if (logcur + nofresh + ncommit > log_cap) { over = true; h.nb = 0; return 2; }
             if (me < ncommit) { const unsigned idx = run_begin + nofresh + me; A.logbuf[4ull * idx] = myS; A.logbuf[4ull * idx + 2] = 0u; memo[myS] = idx + 1; }
-            if (js < 0) { wv.fence(); nofresh += nb; nb = 0; return 0; }
+            if (js < 0) { wv.fence(); nofresh += nb; h.nb = 0; flush_mark = h.steps; return 0; }
             // the reference would have stopped at pending state js: roll the step counter back to it
             const unsigned ev_mi = wv.bcast(dup ? run_begin + nofresh + dsrc + 1u : mi, js), ev_en = wv.bcast(dup ? 0u : en, js);
             nofresh += (unsigned)js;
-            steps = steps_b + (unsigned)js + 1;
+            h.steps = steps_b + (unsigned)js + 1;
             const unsigned i = ev_mi - 1;
-            const unsigned long long R = (unsigned long long)g2 + 1ull - steps;             // points still to come until the guard fires
+            const unsigned long long R = (unsigned long long)g2 + 1ull - h.steps;           // points still to come until the guard fires
             if (ev_en != 0) d_hit++; else d_det++;
             // committed trajectory of an earlier walk: this run's own no-fresh states become a transient record that runs into entry i, so
             // later walks can jump from them too.  A state of this very run: the cycle [i, run_begin + nofresh) is closed.
@@ -361,46 +608,56 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             }
             wv.fence();                                       // provisional entries and the record are in memory before anything reads the log
             tail_i1 = ev_mi; tail_R = (unsigned)R; tail_len = R;
-            int ex, ey; log_pos(i, R, ex, ey); wv.set_cursor(ex, ey);
-            nb = 0;
+            wv.set_cursor(log_pos(i, R));
+            h.nb = 0;
             return 1;
         };
-        int ended = 0, kopp = 8;
+        auto flush = [&]() -> int { const unsigned long long t_0 = WPROF_NOW(); n_flush++; const int r = flush_(); WPROF_ADD(t_flush, t_0); return r; };
+        int ended = 0;
         while (true) {
-            unsigned m_any, m_unvis;
-            wv.probe(kopp, m_any, m_unvis);
-            const bool fresh = m_unvis != 0;
-            const unsigned m = fresh ? m_unvis : m_any;
-            if (!m) break;
-            if (fresh && nb) { ended = flush(); if (ended) break; }
-            const int k = ffs8(m);
-            if (!fresh && nb == 0) steps_b = steps;
-            if (steps < room) wv.put_code(slog, room, steps, k); else over = true;
-            steps++;
-            wv.step(k, fresh);
-            kopp = 7 - k;
-            if (wv.px == x0 && wv.py == y0) break;
-            if (steps > g2) break;
-            if (fresh) { nofresh = 0; nbatch = nbatch0; continue; }
-            if (wv.l0() == nb) myS = (wv.pl << 3) | (unsigned)k;
-            nb++;
-            if (nb == nbatch) { ended = flush(); if (ended) break; nbatch = nbatch * 2u < wv.nl() ? nbatch * 2u : wv.nl(); }
+            if (h.steps >= room) { over = true; break; }
+            unsigned lim = (h.steps & ~63u) + 64u;                    // the records of 64 steps fit the lanes: codes and marks leave at every multiple of 64
+            if (lim > g2 + 1u) lim = g2 + 1u;
+            if (lim > room) lim = room;
+            h.limit = lim;
+            int ev = wv.run(h, slog, room);
+            n_ev++;
+            if (ev == EV_DEAD) {
+                const int f = wv.resume_flagged(h.steps);             // GPU: a flagged window cell stops the loop the same way
+                if (f == 1) continue;                                 // window re-placed
+                if (f == 0) break;                                    // no neighbour at all (04:187-188)
+                ev = EV_HOME;
+            }
+            if (ev == EV_HOME) { drop = h.nb ? 1u : 0u; break; }      // back on the start pixel (04:196): checked before the state of that step counts
+            if (ev == EV_PEND) { ended = flush(); if (ended) break; continue; }
+            if (ev == EV_LIMIT) {
+                if ((h.steps & 63u) == 0) wv.flush_codes(slog, room, h.steps);
+                if (h.steps > g2) { drop = h.nb ? 1u : 0u; break; }   // guard (04:199), also checked before the state of that step counts
+                if (h.nb < h.nbatch) continue;                        // (the step that filled the code window may have filled the batch too)
+            }
+            // EV_BATCH
+            ended = flush(); if (ended) break;
+            h.nbatch = h.nbatch * 2u < wv.nl() ? h.nbatch * 2u : wv.nl();
         }
-        if (!ended && nb) ended = flush();
-        wv.finish_codes(slog, room, steps);
-        wv.sync_marks();
+        if (!ended && h.nb > drop) ended = flush();
+        wv.flush_codes(slog, room, h.steps);
+        wv.sync_marks(h.steps);
         if (ended == 2) break;
+        const unsigned steps = h.steps;
         stepcur += steps; d_s2 += steps;
         unsigned long long len = 1ull + steps + tail_len;
         unsigned flags = 0;
         if (len >= 2) {
-            int ddx = x0 - wv.px, ddy = y0 - wv.py;
+            const int ddx = (int)(s % (unsigned)W) - (int)(wv.pl % (unsigned)W), ddy = (int)(s / (unsigned)W) - (int)(wv.pl / (unsigned)W);
             if (ddx * ddx + ddy * ddy < 3) { flags = 1; len++; }   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}: the start is appended again
         }
         finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
     }
     if (over && wv.leader()) *A.overflow = 1;
-    if (A.dbg && wv.leader()) { unsigned long long* d = A.dbg + 8ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg; }
+    if (A.dbg && wv.leader()) {
+        unsigned long long* d = A.dbg + 16ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
+        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev;     // cycle counts: ORIP_WALK_PROF builds only
+    }
 }
 
 // Points of one recorded walk (winfo slot `slot`), written by one wavefront.
