@@ -139,9 +139,14 @@ __global__ __launch_bounds__(64) void k_trace(WalkArgs A) {
 __global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, const unsigned* __restrict__ kept_slots, unsigned n_kept) {
     for (unsigned i = blockIdx.x; i < n_kept; i += gridDim.x) write_walk(A, kept_slots[i]);
 }
-__global__ __launch_bounds__(256) void k_winfo_lens(const WalkInfo* __restrict__ wi, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
+// lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here
+__global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { unsigned l = wi[i].len_kept; lens[i] = l; kept[i] = l ? 1u : 0u; }
+    if (i < n) {
+        WalkInfo w = A.winfo[slot0 + i];
+        if (w.flags & 2u) { walk_close_tail(A, PlainReader(), slot0 + i, w); A.winfo[slot0 + i] = w; }
+        lens[i] = w.len_kept; kept[i] = w.len_kept ? 1u : 0u;
+    }
     if (i == n) { lens[i] = 0; kept[i] = 0; }
 }
 
@@ -473,13 +478,19 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
                 layer, NCl, Ml, R.F[layer], tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
         if (d[8]) fprintf(stderr, "[walk prof] layer %d largest component: cycles total=%llu window loads=%llu scans=%llu look-ups=%llu | look-ups=%llu loop exits=%llu\n",
                           layer, d[8], d[9], d[10], d[11], d[12], d[13]);
+        if (d[8]) fprintf(stderr, "[walk prof]   inside the look-ups: duplicate check %llu cycles\n", d[14]);
     }
     // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
     const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
     HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
     unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1);
     unsigned* kept = (unsigned*)(pts_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
-    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, R.A.winfo + sl0, nslots, lens, kept);
+    {
+        WalkArgs A = R.A;                    // the layer's logs as the trace addressed them (walk_close_tail follows the recorded trajectories)
+        A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)R.F[layer] * b0 + (size_t)64 * c0);
+        A.cap_factor = R.F[layer];
+        hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, lens, kept);
+    }
     ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, (size_t)nslots + 1, LN(c).tmpF));
     ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, (size_t)nslots + 1, LN(c).tmpF));
     unsigned long long h_pts = 0; unsigned h_paths = 0;

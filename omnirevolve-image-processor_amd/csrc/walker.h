@@ -289,6 +289,20 @@ struct Wave {
     __device__ void log_code(u8*, unsigned, unsigned, int) {}      // the record of the step carries its code
     __device__ unsigned bcast(unsigned x, int src) const { return (unsigned)__shfl((int)x, src, 64); }
     __device__ int first(bool pred) const { unsigned long long m = __ballot(pred); return m ? __ffsll((long long)m) - 1 : -1; }
+    // key: this lane's pending state + 1 (0: none).  Smallest d in [1, n) with key(lane - d) == key(lane), 0 if there is none: the keys
+    // slide down the wave one lane per round (DPP wave_shr:1, zeros come in at lane 0), four rounds per loop trip; no LDS, no branches.
+    __device__ unsigned dup_distance(unsigned key, unsigned n) const {
+        unsigned t = key, best = ~0u;
+        for (unsigned d = 1; d < n; d += 4) {
+#pragma unroll
+            for (unsigned u = 0; u < 4; u++) {
+                t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                const unsigned cand = t == key ? d + u : ~0u;
+                best = cand < best ? cand : best;
+            }
+        }
+        return (key != 0 && best != ~0u) ? best : 0u;
+    }
     // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
     __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q += 64) {
@@ -468,6 +482,7 @@ struct Wave {
     }
     unsigned bcast(unsigned v, int) const { return v; }
     int first(bool pred) const { return pred ? 0 : -1; }
+    unsigned dup_distance(unsigned, unsigned) const { return 0u; }       // one pending state at most
     unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
         for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) return q; }
         return e;
@@ -481,6 +496,11 @@ ORIP_HD inline int nbx(int k) { return (int)((0x9224u >> (2 * k)) & 3u) - 1; }
 ORIP_HD inline int nby(int k) { return (int)((0xA940u >> (2 * k)) & 3u) - 1; }
 }  // namespace walk_detail
 
+// reader of log records for code that runs one thread per walk (not one wave)
+struct PlainReader {
+    ORIP_HD void ld0_rec(const unsigned* p, unsigned& cont, unsigned& en, unsigned& begin) const { cont = p[1]; en = p[2]; begin = p[3]; }
+};
+
 // Entry reached from the record of entry `rec` at raw position f (f >= rec): follow continuations until f lies inside a record.
 template <class WaveT>
 ORIP_HD inline unsigned long long log_resolve(const unsigned* logbuf, const WaveT& wv, unsigned rec, unsigned long long f) {
@@ -490,6 +510,29 @@ ORIP_HD inline unsigned long long log_resolve(const unsigned* logbuf, const Wave
         if (cont >= begin) return (unsigned long long)cont + (f - en) % (unsigned long long)(en - cont);   // cycle
         f = (unsigned long long)cont + (f - en); rec = cont;                                               // transient -> older record
     }
+}
+
+// 04:201-204: a path whose end lies within 1.5 px of its start gets the start appended again (integers: squared distance 0, 1 or 2)
+ORIP_HD inline bool close_to(int W, unsigned a, unsigned b) {
+    const int ddx = (int)(a % (unsigned)W) - (int)(b % (unsigned)W), ddy = (int)(a / (unsigned)W) - (int)(b / (unsigned)W);
+    return ddx * ddx + ddy * ddy < 3;
+}
+
+// A walk that ended by jumping into a recorded trajectory (flags bit 1) has its end point R steps down that trajectory: following the
+// records costs a few dependent loads, which the serial trace does not wait for -- one thread per such walk does it afterwards
+// (k_winfo_lens on the GPU) and settles the closing point: returns the final WalkInfo length and flags.
+template <class WaveT>
+ORIP_HD inline void walk_close_tail(const WalkArgs& A, const WaveT& wv, unsigned slot, WalkInfo& wi) {
+    if (!(wi.flags & 2u)) return;
+    unsigned lo = 0, hi = A.nc;
+    while (lo < hi) { unsigned mid = (lo + hi) >> 1; if (2u * A.comp_start[mid + 1] <= slot) lo = mid + 1; else hi = mid; }
+    const unsigned b = A.comp_start[lo], fg = A.comp_start[lo + 1] - b, rel = slot - 2u * b;
+    const unsigned s = A.lin[b + (rel >= fg ? rel - fg : rel)];
+    const unsigned i = wi.log_i1 - 1;
+    const unsigned long long f = log_resolve(A.logbuf, wv, i, (unsigned long long)i + wi.R);
+    const unsigned endp = A.logbuf[4ull * f] >> 3;
+    wi.flags = 0;
+    if (close_to(A.W, s, endp)) { wi.flags = 1; wi.len_kept++; }
 }
 
 ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
@@ -508,7 +551,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     unsigned logcur = 0, stepcur = 0;
     bool over = false;
     unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
-    unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
+    unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0, t_f3 = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
         if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
     };
@@ -543,10 +586,6 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         finish(2u * b + (q - b), 1ull + steps, steps, sbeg, 0u, 0u, 0u);
     }
     // ---- phase 2: leftovers / cycles (04:174-205)
-    auto log_pos = [&](unsigned i, unsigned long long R) -> unsigned {   // pixel (linear index) R steps after logged state i
-        unsigned long long f = log_resolve(A.logbuf, wv, i, (unsigned long long)i + R);
-        return wv.ld0(&A.logbuf[4ull * f]) >> 3;
-    };
     // A walk that finds no fresh neighbour is on a trajectory that only depends on its state (pixel, incoming direction), so its
     // states are looked up in / added to the memo.  The memo lives in HBM and a look-up per step would put one full memory latency
     // on every step of a strictly serial chain; instead the walk runs ahead on the LDS window (Wave::run) and keeps its no-fresh
@@ -571,44 +610,56 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         unsigned nofresh = 0;                 // no-fresh states logged since the last fresh pixel: entries [run_begin, run_begin + nofresh)
         unsigned flush_mark = 0;              // h.steps when the last look-up returned: a later pending state that starts beyond it follows a fresh step
         unsigned drop = 0;                    // 1: the walk ended on the step of the last pending state (start pixel / guard), which the reference does not look at
+        // Provisional entries of a run that did not end in a known trajectory are taken out of the memo again, so that a non-zero memo
+        // word always names a valid entry: below run_begin a committed one, from run_begin on one of the run in progress.  A look-up is
+        // then ONE load (the word itself), not the word plus the log entry it points to -- half the memory latency of the serial chain.
+        auto discard_run = [&]() {
+            if (nofresh) {
+                const unsigned run_begin = log_base + logcur;
+                for (unsigned t = wv.l0(); t < nofresh; t += wv.nl()) memo[A.logbuf[4ull * (run_begin + t)]] = 0u;
+                wv.fence();
+                nofresh = 0;
+            }
+        };
         // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow
         auto flush_ = [&]() -> int {
             const unsigned nb = h.nb - drop;
             if (!nb) { h.nb = 0; return 0; }
             const unsigned steps_b = h.steps - h.nb;                  // steps before the first pending state
-            if (steps_b > flush_mark) { nofresh = 0; h.nbatch = nbatch0; }      // a fresh pixel since the last look-up: a new run
+            if (steps_b > flush_mark) { discard_run(); h.nbatch = nbatch0; }      // a fresh pixel since the last look-up: a new run
             const unsigned myS = wv.pending(steps_b);                 // lane j: j-th pending state
             const unsigned run_begin = log_base + logcur;
             const unsigned me = wv.l0();
             const bool act = me < nb;
-            unsigned mi = 0, ld = 0, en = 0;
+            wv.fence();                                               // entries written by the previous look-up (long done by now)
+            unsigned mi = 0;
             if (act) mi = memo[myS];
-            if (act && mi) { ld = A.logbuf[4ull * (mi - 1)]; en = A.logbuf[4ull * (mi - 1) + 2]; }
-            const bool hit_old = act && mi && ld == myS && (en != 0 || (mi - 1 >= run_begin && mi - 1 < run_begin + nofresh));
-            bool dup = false; unsigned dsrc = 0;                                             // latest earlier pending state equal to mine
-            for (unsigned jp = 0; jp + 1 < nb; jp++) { const unsigned sj = wv.bcast(myS, (int)jp); if (act && me > jp && myS == sj) { dup = true; dsrc = jp; } }
+            const unsigned long long t_c = WPROF_NOW();
+            const unsigned dist = wv.dup_distance(act ? myS + 1u : 0u, nb);                  // distance to the latest earlier pending state equal to mine (0: none)
+            const bool dup = act && dist != 0; const unsigned dsrc = me - dist;
+            t_f3 += WPROF_NOW() - t_c;
+            const bool hit_old = act && mi != 0;
             const int js = wv.first(hit_old || dup);
             const unsigned ncommit = js < 0 ? nb : (unsigned)js;
             if (logcur + nofresh + ncommit > log_cap) { over = true; h.nb = 0; return 2; }
-            if (me < ncommit) { const unsigned idx = run_begin + nofresh + me; A.logbuf[4ull * idx] = myS; A.logbuf[4ull * idx + 2] = 0u; memo[myS] = idx + 1; }
-            if (js < 0) { wv.fence(); nofresh += nb; h.nb = 0; flush_mark = h.steps; return 0; }
+            if (me < ncommit) { const unsigned idx = run_begin + nofresh + me; A.logbuf[4ull * idx] = myS; memo[myS] = idx + 1; }
+            if (js < 0) { nofresh += nb; h.nb = 0; flush_mark = h.steps; return 0; }
             // the reference would have stopped at pending state js: roll the step counter back to it
-            const unsigned ev_mi = wv.bcast(dup ? run_begin + nofresh + dsrc + 1u : mi, js), ev_en = wv.bcast(dup ? 0u : en, js);
+            const unsigned ev_mi = wv.bcast(dup ? run_begin + nofresh + dsrc + 1u : mi, js);
             nofresh += (unsigned)js;
             h.steps = steps_b + (unsigned)js + 1;
             const unsigned i = ev_mi - 1;
             const unsigned long long R = (unsigned long long)g2 + 1ull - h.steps;           // points still to come until the guard fires
-            if (ev_en != 0) d_hit++; else d_det++;
+            if (i < run_begin) d_hit++; else d_det++;
             // committed trajectory of an earlier walk: this run's own no-fresh states become a transient record that runs into entry i, so
             // later walks can jump from them too.  A state of this very run: the cycle [i, run_begin + nofresh) is closed.
             if (nofresh) {
                 const unsigned end = run_begin + nofresh;
                 for (unsigned t = me; t < nofresh; t += wv.nl()) { unsigned* p = A.logbuf + 4ull * (run_begin + t); p[1] = i; p[2] = end; p[3] = run_begin; }
                 logcur += nofresh;
+                nofresh = 0;                                  // committed: nothing to discard
             }
-            wv.fence();                                       // provisional entries and the record are in memory before anything reads the log
             tail_i1 = ev_mi; tail_R = (unsigned)R; tail_len = R;
-            wv.set_cursor(log_pos(i, R));
             h.nb = 0;
             return 1;
         };
@@ -641,22 +692,21 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         }
         if (!ended && h.nb > drop) ended = flush();
         wv.flush_codes(slog, room, h.steps);
+        if (ended != 1) discard_run();                                // a run that never reached a known trajectory stays out of the memo
         wv.sync_marks(h.steps);
         if (ended == 2) break;
         const unsigned steps = h.steps;
         stepcur += steps; d_s2 += steps;
         unsigned long long len = 1ull + steps + tail_len;
         unsigned flags = 0;
-        if (len >= 2) {
-            const int ddx = (int)(s % (unsigned)W) - (int)(wv.pl % (unsigned)W), ddy = (int)(s / (unsigned)W) - (int)(wv.pl / (unsigned)W);
-            if (ddx * ddx + ddy * ddy < 3) { flags = 1; len++; }   // hypot < 1.5 on integers  <=>  d2 in {0,1,2}: the start is appended again
-        }
+        if (ended == 1) flags = 2;                                    // the end point lies in the recorded trajectory: walk_close_tail decides about the closing point
+        else if (len >= 2 && close_to(W, s, wv.pl)) { flags = 1; len++; }
         finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
     }
     if (over && wv.leader()) *A.overflow = 1;
     if (A.dbg && wv.leader()) {
         unsigned long long* d = A.dbg + 16ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
-        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev;     // cycle counts: ORIP_WALK_PROF builds only
+        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3;     // cycle counts: ORIP_WALK_PROF builds only
     }
 }
 

@@ -56,6 +56,7 @@ extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out,
     for (unsigned c = 0; c < NC; c++) trace_component(A, c);
     if (over) return 2;     // the product retries with a larger factor; the test asks for one explicitly
     const unsigned nslots = 2 * M;
+    for (unsigned i = 0; i < nslots; i++) walk_close_tail(A, PlainReader(), i, winfo[i]);      // what k_winfo_lens does on the GPU
     std::vector<unsigned long long> pts_off(nslots + 1, 0); std::vector<unsigned> path_off(nslots + 1, 0);
     for (unsigned i = 0; i < nslots; i++) { pts_off[i + 1] = pts_off[i] + winfo[i].len_kept; path_off[i + 1] = path_off[i] + (winfo[i].len_kept ? 1u : 0u); }
     *n_paths = path_off[nslots]; *n_pts = (int64_t)pts_off[nslots];
