@@ -3,22 +3,28 @@
 synthetic 4096 x 4096, 8-layer image (BASELINE.json; SURVEY 8(d) generator, seed 20251121).
 
   python bench.py --gpus N --steps K --warmup W          (N > 1 is launched by torch.distributed.run, one rank per GPU)
+  python bench.py --size 2048 --upto 3                    (BASELINE config C2: stages 02 + 03 only, raster kernels vs the HBM roofline)
 
 A "step" is one pass of the whole hot path over one image whose pixels are already resident in HBM (orip_set_image is
-outside the timed region; the PCIe-inclusive figure is in DESIGN.md).  Nothing is cached between steps: every step
-re-runs the k-means fit, all raster stages, the contour walk, both dedup stages and the plot ordering; the ops stay on
-the GPU.  With N > 1 the single image is processed by all ranks together (colour-layer sharding), so the
-scaling is "strong"; the timed region is bracketed by a barrier + device sync and the max over ranks is reported.
+outside the timed region).  Nothing is cached between steps: every step re-runs the k-means fit, all raster stages, the
+contour walk, both dedup stages and the plot ordering; the op rows come back to the host, the line points stay on the GPU.
+With N > 1 the single image is processed by all ranks together (colour-layer sharding), so the scaling is
+"strong"; the timed region is bracketed by a barrier + device sync and the max over ranks is reported.
 
 One JSON line on rank 0.  Extra objects:
+  inclusive    -- the same step with the upload of the image and the fetch of every op list AND its line points inside the
+                  timed region: SURVEY 8(d)'s definition "host pixels -> ops lists in host memory" (PCIe-inclusive; never `value`)
   roofline     -- the kernel group with the largest device time in a profiled step: algorithmic bytes (DESIGN.md
                   "Algorithmic bytes") / mean duration measured with HIP events on the library's own stream
-  kernel_groups-- the same figures for every raster kernel group, for reference
-  cpu_baseline -- the CPU restatement (oracle/, "port") on a 512 x 512 crop of the same image, all 8 layers, stages 02->12
+  kernel_groups-- the same figures for every raster kernel group
+  cpu_baseline -- the CPU restatement (oracle/, "port") on the top-left 1024 x 1024 crop of the same image, all layers, stages
+                  02 -> 12: single-threaded, and with min(K, nproc) layer threads (the reference's only parallelism, 03:42-48)
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -30,26 +36,40 @@ sys.path.insert(0, os.path.join(ROOT, "omnirevolve-image-processor_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def csrc_digest() -> str:
+    """identifies the kernel sources a PMC file was collected on (tools/pmc_traffic.py stores the same digest)"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "omnirevolve-image-processor_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def kernel_groups(H, W, K, n_points):
-    """name -> (kernels, algorithmic bytes, per, note).  per == "launch": bytes of ONE launch of the (single) kernel; per == "step":
-    bytes the whole group moves in one step (its kernels run once per layer).  DESIGN.md 'Algorithmic bytes'."""
+    """name -> (HIP-event labels, algorithmic bytes, per, note).  per == "launch": bytes of ONE launch of the (single) kernel;
+    per == "step": bytes the whole group moves in one step (its kernels run once per layer).  DESIGN.md 'Algorithmic bytes'."""
     px = H * W
     return {
         "lab_assign": (["k_lab_assign"], 4 * px, "launch", "3 B BGR in + 1 B label out per pixel"),
         "morph_pass": (["k_morph_pass"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and pass (byte kernel: non-binary masks only)"),
         "morph_bits": (["k_morph_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and pass; the bit planes (2 MB per layer) stay in L2, "
                        "so this is cache traffic, not HBM traffic"),
-        "blur_sobel_nms": (["k_blur_sobel_nms"], K * px + K * px // 4, "launch", "1 B mask in + 2 bits (candidate, strong planes) out per pixel per layer"),
-        "thin_sub": (["k_thin_sub"], 2 * K * px, "launch", "1 B in + 1 B out per pixel per layer and sub-iteration (byte kernel, ORIP_THIN_BYTES only)"),
+        "blur_sobel_nms": (["k_blur_sobel_nms"], K * px // 8 + K * px // 4, "launch", "1 bit mask in + 2 bits (candidate, strong planes) out per pixel per layer"),
         "thin_bits": (["k_thin_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and sub-iteration; bit planes of 2 MB per layer: cache traffic"),
-        "ccl_merge": (["k_ccl_merge"], 5 * K * px, "launch", "1 B image + 4 B parent per pixel per layer"),
+        "skel_state": (["k_skel_state"], K * px // 8 + 2 * K * px, "launch", "1 bit in + skeleton byte + state byte out per pixel per layer"),
         "stage04_write": (["k_write_walks"], 8 * n_points, "step", "8 B per emitted contour point (SURVEY 8d), one launch per layer"),
         "stage04_trace": (["k_trace", "k_write_walks"], K * px + 8 * n_points, "step",
                           "K B/px skeleton state read once + 8 B per emitted contour point (SURVEY 8d); k_trace is a serial dependent chain "
                           "per skeleton component (one wave each), so its time is latency, not bandwidth"),
     }
+
+
+# HIP-event label -> kernel names as rocprofv3 reports them (for the PMC cross-check)
+PMC_NAMES = {"k_trace": ["k_trace"], "k_write_walks": ["k_write_walks"], "k_lab_assign": ["k_lab_assign"], "k_blur_sobel_nms": ["k_blur_sobel_nms"],
+             "k_morph_bits": ["k_morph_bits"], "k_thin_bits": ["k_thin_bits04"], "k_skel_state": ["k_bits_to_skel_state"]}
 
 
 def main():
@@ -59,13 +79,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096, help="image side (BASELINE: 4096)")
     ap.add_argument("--layers", type=int, default=8, help="colour layers (BASELINE: 8)")
+    ap.add_argument("--upto", type=int, default=12, choices=[3, 12], help="3: stages 02 + 03 only (BASELINE config C2, use with --size 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    dist = None; coll_device = None
+    dist = None; coll_device = None; backend = None; n_vis = 1
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -84,12 +105,14 @@ def main():
     from orip.device import Device
     from orip import lib as L
     from orip import parallel as P
+    from orip import stages as S
     from orip.synth import synth_image, layer_names
 
     H = W = args.size; K = args.layers
     img = synth_image(H, W, K)
     cfg = Config(); cfg.color_names = layer_names(K)
     dev = Device(local_rank)
+    comm = P.make_comm(dev, rank, world, coll_device) if world > 1 else None
     dev.set_image(img)      # input resident in HBM before the timed region
 
     def barrier():
@@ -98,8 +121,14 @@ def main():
             dist.barrier()
         dev.sync()
 
-    def step():
-        return P.run_path_sharded(dev, cfg, H, W, rank, world, coll_device)
+    def step(fetch=False):
+        if args.upto == 3:
+            centers, _ = dev.kmeans_fit(S.subsample_indices(H * W), K)
+            dev.extract_layers(centers, want_counts=False)
+            S._detect_edges_resident(dev, cfg)
+            dev.sync()
+            return 0
+        return P.run_path_sharded(dev, cfg, H, W, rank, world, coll_device, fetch_lines=fetch, comm=comm)
 
     for _ in range(args.warmup):
         step()
@@ -110,13 +139,32 @@ def main():
         n_ops = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed / max(1, args.steps) * 1e3
     value = (H * W / 1e6) * args.steps / elapsed
+
+    # ---- inclusive leg: host pixels -> every op list and its line points in host memory, same barrier bracket
+    inclusive = None
+    if args.upto == 12:
+        n_inc = max(1, min(3, args.steps))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_inc):
+            dev.set_image(img)
+            step(fetch=True)
+        barrier()
+        inc = max_over_ranks(time.perf_counter() - t1)
+        inclusive = {"ms_per_step": round(inc / n_inc * 1e3, 2), "value": round((H * W / 1e6) * n_inc / inc, 4), "unit": "Mpx/s", "steps": n_inc,
+                     "note": "upload of the 3 B/px image + the path + fetch of every layer's op rows and line points, per step (PCIe inclusive)"}
 
     # ---- roofline leg: one extra profiled step (HIP events around every launch on the library's stream); not timed above
     roofline = None; groups_out = {}
@@ -125,8 +173,8 @@ def main():
     step()          # every rank takes part (the step holds collectives when N > 1); only rank 0 records events
     if rank == 0:
         dev.prof_enable(False)
-        n_points = sum(dev.polys_size(L.SLOT_CONTOURS, l)[1] for l in range(K if world == 1 else len(P.owned_layers(K, rank, world))))
         Keff = K if world == 1 else len(P.owned_layers(K, rank, world))
+        n_points = sum(dev.polys_size(L.SLOT_CONTOURS, l)[1] for l in range(Keff)) if args.upto == 12 else 0
         best = None
         for name, (kernels, nbytes, per, note) in kernel_groups(H, W, Keff, n_points).items():
             tot_ms = 0.0; launches = 0
@@ -143,44 +191,61 @@ def main():
                 best = name
         if best:
             e = groups_out[best]
-            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; rocprofv3 cannot run
-            # inside the timed process).  FETCH_SIZE is the raw counter: on gfx950 it shows half the bytes of wide coalesced reads and is
-            # uncalibrated for the byte/dword-granular reads of the walk; WRITE_SIZE is exact.
+            # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py; rocprofv3 cannot run
+            # inside the timed process).  The file is only believed when it was collected on exactly these kernel sources.
             traffic = None; traffic_note = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                if all(k in pm for k in e["kernels"]) and H == 4096 and K == 8 and world == 1:
-                    traffic = int(sum(pm[k]["fetch_bytes_per_launch_raw"] + pm[k]["write_bytes_per_launch"] for k in e["kernels"]))
-                    traffic_note = "profiles/r01_pmc_traffic.json: FETCH_SIZE (raw) + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of this command"
-            except (OSError, KeyError, ValueError):
-                pass
+                pmf = json.load(open(PMC_FILE))
+                names = [n for k in e["kernels"] for n in PMC_NAMES.get(k, [k])]
+                if pmf.get("csrc_digest") != csrc_digest():
+                    traffic_note = f"{os.path.relpath(PMC_FILE, ROOT)} was collected on other kernel sources (digest {pmf.get('csrc_digest')} != {csrc_digest()}): refused"
+                elif not all(n in pmf["kernels"] for n in names) or not (H == 4096 and K == 8 and world == 1 and args.upto == 12):
+                    traffic_note = f"{os.path.relpath(PMC_FILE, ROOT)} does not cover this configuration / these kernels: refused"
+                else:
+                    traffic = int(sum(2 * pmf["kernels"][n]["fetch_bytes_per_launch_raw"] + pmf["kernels"][n]["write_bytes_per_launch"] for n in names))
+                    traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE "
+                                    "per launch, separate rocprofv3 --pmc passes of this command")
+            except (OSError, KeyError, ValueError) as ex:
+                traffic_note = f"no usable PMC file ({type(ex).__name__})"
             roofline = {"kernel": "+".join(e["kernels"]), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": e["frac"], "traffic": traffic, "traffic_note": traffic_note, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
 
-    # ---- CPU baseline leg (rank 0, N = 1 only): the oracle as a "port", bounded sample
+    # ---- CPU baseline legs (rank 0, N = 1 only): the oracle as a "port", bounded sample, single thread and layer threads
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        crop = min(512, H)
+        crop = min(1024, H)
         sub = np.ascontiguousarray(img[:crop, :crop])
-        t = time.perf_counter()
-        O.run_pipeline(sub, dict(O.DEFAULTS, color_names=layer_names(K)))
-        dt = time.perf_counter() - t
-        cpu = {"value": round(crop * crop / 1e6 / dt, 5), "unit": "Mpx/s", "cores": 1, "kind": "port",
-               "sample": f"top-left {crop}x{crop} crop of the bench image ({crop * crop / (H * W):.4f} of the pixels), all {K} layers, stages 02->12, "
-                         f"single thread, {dt:.1f} s"}
+        ocfg = dict(O.DEFAULTS, color_names=layer_names(K))
+        nproc = os.cpu_count() or 1
+        t = time.perf_counter(); O.run_pipeline(sub, ocfg, upto=args.upto); dt1 = time.perf_counter() - t
+        nthr = max(1, min(K, nproc))
+        t = time.perf_counter(); O.run_pipeline(sub, ocfg, upto=args.upto, threads=nthr); dtn = time.perf_counter() - t
+        mpx = crop * crop / 1e6
+        cpu = {"value": round(mpx / dt1, 5), "unit": "Mpx/s", "cores": 1, "kind": "port",
+               "sample": f"top-left {crop}x{crop} crop of the bench image ({crop * crop / (H * W):.4f} of the pixels), all {K} layers, stages 02->{args.upto}, "
+                         f"single thread, {dt1:.1f} s",
+               "layer_parallel": {"value": round(mpx / dtn, 5), "unit": "Mpx/s", "cores": nthr, "nproc": nproc, "seconds": round(dtn, 1),
+                                  "note": "stages 03-08 of different layers in min(K, nproc) threads, stages 02 / 10 / 12 serial (the reference only "
+                                          "parallelises over layers, 03:42-48)"}}
 
     if rank == 0:
+        stages = "stages 02->12 (k-means fit, masks, edges, contours, scale, sort, intra dedup, cross dedup, plot order), default A4 canvas 8400x11880" \
+            if args.upto == 12 else "stages 02+03 only (k-means fit, label assignment, masks, morphology, blur, Canny): BASELINE config C2"
         out = {
-            "metric": "Mpx/s end-to-end (color->order)", "value": round(value, 4), "unit": "Mpx/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "metric": "Mpx/s end-to-end (color->order)", "value": round(value, 4), "unit": "Mpx/s",
+            "n_gpus": min(world, max(1, n_vis)) if world > 1 else 1, "ranks": world, "backend": backend or "none",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8/i32 raster + f32/f64 geometry", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} BGR image, {K} colour layers, stages 02->12 (k-means fit, masks, edges, contours, scale, sort, "
-                                   f"intra dedup, cross dedup, plot order), default A4 canvas 8400x11880", "parallelism": f"layer-sharded x{args.gpus}",
-                       "ops_last_step_rank0": int(n_ops)},
-            "roofline": roofline, "kernel_groups": groups_out, "cpu_baseline": cpu,
+            "config": {"workload": f"{W}x{H} BGR image, {K} colour layers, {stages}", "parallelism": f"layer-sharded x{args.gpus}",
+                       "ops_last_step_rank0": int(n_ops), "exchange": (comm.kind if comm is not None else "none")},
+            "inclusive": inclusive, "roofline": roofline, "kernel_groups": groups_out, "cpu_baseline": cpu,
         }
+        if world > 1 and n_vis < world:
+            out["note"] = f"{world} ranks shared {n_vis} visible GPU(s) (gloo rehearsal): NOT a multi-GPU scaling point"
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     dev.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

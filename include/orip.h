@@ -127,6 +127,18 @@ int orip_dedup_cross_layer_from(orip_ctx* ctx, int src_layer, int layer);
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);
 int orip_get_ops(orip_ctx* ctx, int layer, int32_t* ops5);
 
+/* ---- multi-GPU exchange (no counterpart in the reference, which is a single process) ----
+ * One process per GPU; rank r owns the cluster layers {l : l % world == r} for stages 03-08 and 12.  Stage 10 is replicated and needs
+ * every layer's stage-08 lists (10:236-267): orip_bcast_layer sends LINES_INTRA / TAPS_INTRA of one layer from its owner to all ranks
+ * with RCCL broadcasts over xGMI, device to device.  The unique id is created on rank 0 and handed to the other processes by the
+ * launcher (any out-of-band channel: bench.py uses its torch.distributed store). */
+#define ORIP_COMM_ID_BYTES 128
+int orip_comm_unique_id(uint8_t* id_out /* [ORIP_COMM_ID_BYTES] */);
+int orip_comm_init(orip_ctx* ctx, const uint8_t* id, int rank, int world);
+int orip_comm_destroy(orip_ctx* ctx);
+/* collective: every rank passes the slot index under which IT holds / receives the layer */
+int orip_bcast_layer(orip_ctx* ctx, int root, int my_slot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ extern "C" void orip_destroy(orip_ctx* c) {
     for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
     orip_contours_free(c);
+    orip_comm_destroy(c);
+    c->comm_sizes.release();
     delete c;
 }
 

@@ -121,6 +121,9 @@ struct orip_ctx {
     DTaps taps[2][ORIP_MAX_LAYERS];
     DBuf ops[ORIP_MAX_LAYERS];
     int64_t n_ops[ORIP_MAX_LAYERS] = {0};
+    // multi-GPU exchange (comm.hip): RCCL communicator of this process, device row for the list sizes
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+    DBuf comm_sizes;
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;

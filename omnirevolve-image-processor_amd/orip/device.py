@@ -209,6 +209,24 @@ class Device:
         else:
             self._ck(self.L.orip_dedup_cross_layer_from(self.h, src_layer, layer))
 
+    # ---- multi-GPU exchange (RCCL inside liborip.so)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * _l.COMM_ID_BYTES)()
+        if self.L.orip_comm_unique_id(buf) != 0:
+            raise OripError("orip_comm_unique_id failed (RCCL)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == _l.COMM_ID_BYTES
+        buf = (C.c_uint8 * _l.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self.L.orip_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._ck(self.L.orip_comm_destroy(self.h))
+
+    def bcast_layer(self, root: int, my_slot: int):
+        self._ck(self.L.orip_bcast_layer(self.h, int(root), int(my_slot)))
+
     def plot_order(self, layer: int, R_insert: float) -> np.ndarray:
         n = C.c_int64(0)
         self._ck(self.L.orip_plot_order(self.h, layer, float(R_insert), C.byref(n)))

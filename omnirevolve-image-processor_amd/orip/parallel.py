@@ -1,4 +1,8 @@
-"""Multi-GPU layout of the path: one process per GPU, torch.distributed as plumbing only.
+"""Multi-GPU layout of the path: one process per GPU.  The exchange itself runs inside liborip.so (csrc/comm.hip:
+RCCL broadcasts over xGMI between the device-resident list slots, no host staging, no torch); torch.distributed is plumbing only
+(the launcher's rendezvous, the barrier of bench.py, and the hand-over of the RCCL unique id).  The gloo functions below move the
+same lists through host memory: they are the CPU test double of the exchange (tests/test_parallel_gloo.py) and the rehearsal path
+when several ranks have to share one card (RCCL refuses two ranks on one GPU).
 
 The path shards by COLOUR LAYER.  Stage 02 (k-means fit on the fixed-seed subsample + assignment) is deterministic and
 cheap, so every rank runs it on the whole image instead of row-sharding it and all-gathering the label map.  From the
@@ -106,8 +110,55 @@ def broadcast_layer(lists, owner: int, device=None) -> Lists:
     return unpack_layers(meta.reshape(1, 3), [buf[:n].cpu().numpy()], 1, 1)[0]
 
 
-def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None):
-    """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  Ops stay on the GPU.
+class RcclComm:
+    """The product exchange: orip_bcast_layer (RCCL, device to device).  The unique id travels through the launcher's process group."""
+    kind = "rccl (orip_bcast_layer, device to device)"
+
+    def __init__(self, dev, rank: int, world: int):
+        import torch.distributed as dist
+        box = [dev.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        dev.comm_init(box[0], rank, world)
+        self.dev = dev
+
+    def bcast(self, owner: int, my_slot: int, i_am_owner: bool):
+        self.dev.bcast_layer(owner, my_slot)
+
+    def close(self):
+        self.dev.comm_destroy()
+
+
+class GlooComm:
+    """Test double / rehearsal: the same lists through host memory and torch.distributed (gloo)."""
+    kind = "gloo (host staging; rehearsal / CPU test double)"
+
+    def __init__(self, dev, coll_device="cpu"):
+        self.dev = dev; self.coll_device = coll_device
+
+    def bcast(self, owner: int, my_slot: int, i_am_owner: bool):
+        from . import lib as _l
+        d = self.dev
+        lists = (d.get_polys(_l.SLOT_LINES_INTRA, my_slot), d.get_taps(_l.TAPS_INTRA, my_slot)) if i_am_owner else None
+        lines, taps = broadcast_layer(lists, owner, self.coll_device)
+        if not i_am_owner:
+            d.set_polys(_l.SLOT_LINES_INTRA, my_slot, lines)
+            d.set_taps(_l.TAPS_INTRA, my_slot, taps)
+
+    def close(self):
+        pass
+
+
+def make_comm(dev, rank: int, world: int, coll_device=None):
+    """RCCL when every rank has its own GPU (torch backend nccl), the gloo double otherwise."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        return RcclComm(dev, rank, world)
+    return GlooComm(dev, coll_device or "cpu")
+
+
+def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None, fetch_lines: bool = False, comm=None):
+    """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  The op rows of every owned layer
+    come back to the host; fetch_lines: so do the points of its lines (what ops.pkl holds, 12:206-208).
     world > 1: rank r ends with the lists and ops of its layers owned_layers(K, r, world) under local indices 0..len-1.
 
     world > 1: every rank pipelines its own layers (04 -> 08, one lane each).  Stage 10 is replicated and streamed: the
@@ -124,10 +175,19 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
     dev.extract_layers(centers, want_counts=False)
     order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))
     R = S.r_insert12(cfg)
+
+    def tail(i):
+        ops = dev.plot_order(i, R)
+        if fetch_lines:
+            dev.get_polys_flat(_l.SLOT_LINES_CROSS, i)
+        return ops
+
     if world == 1:
         S._detect_edges_resident(dev, cfg)
-        res = S.run_layer_pipelines(dev, cfg, W, H, range(K), order, 12, lambda g: dev.plot_order(g, R))
+        res = S.run_layer_pipelines(dev, cfg, W, H, range(K), order, 12, tail)
         return sum(len(o) for o in res.values())
+    if comm is None:
+        comm = make_comm(dev, rank, world, coll_device)
     mine = owned_layers(K, rank, world)              # global layer ids; held under local indices 0..len(mine)-1
     ready, errors = {}, []
     if mine:
@@ -152,16 +212,15 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
             i = mine.index(g)
             ready[i].wait()
             failed = bool(errors)
-            lists = ([], []) if failed else (dev.get_polys(_l.SLOT_LINES_INTRA, i), dev.get_taps(_l.TAPS_INTRA, i))
-            broadcast_layer(lists, owner, coll_device)      # the other ranks are waiting in this collective: never skip it
+            if failed:                                  # the other ranks are waiting in the collective: never skip it, send an empty layer
+                dev.set_polys(_l.SLOT_LINES_INTRA, i, []); dev.set_taps(_l.TAPS_INTRA, i, [])
+            comm.bcast(owner, i, True)
             if failed:
                 continue
             dev.dedup_cross_layer(i, src_layer=i)
-            tails.append(pool.submit(dev.plot_order, i, R))
+            tails.append(pool.submit(tail, i))
         else:
-            lines, taps = broadcast_layer(None, owner, coll_device)
-            dev.set_polys(_l.SLOT_LINES_INTRA, stage_slot, lines)
-            dev.set_taps(_l.TAPS_INTRA, stage_slot, taps)
+            comm.bcast(owner, stage_slot, False)
             dev.dedup_cross_layer(stage_slot, src_layer=stage_slot)
     n_ops = sum(len(f.result()) for f in tails)
     if errors:

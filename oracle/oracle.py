@@ -526,8 +526,10 @@ def stage12(lines, taps, cfg=None):
     return build_ops12(lines, taps, max(80.0, cfg["pen_width_px"]))
 
 
-def run_pipeline(bgr: np.ndarray, cfg=None, centers=None, upto: int = 12):
-    """Stages 02 -> `upto` on one image, returning every intermediate artefact."""
+def run_pipeline(bgr: np.ndarray, cfg=None, centers=None, upto: int = 12, threads: int = 1):
+    """Stages 02 -> `upto` on one image, returning every intermediate artefact.  threads > 1: the per-layer stages 03 -> 08 of
+    different layers run in that many threads (the reference's only parallelism is its pool over layers in stage 03, 03:42-48; the
+    C++ calls release the GIL); stages 02, 10 and 12 stay serial as in the reference."""
     cfg = _cfg(cfg)
     names = list(cfg["color_names"])
     h, w = bgr.shape[:2]
@@ -535,16 +537,25 @@ def run_pipeline(bgr: np.ndarray, cfg=None, centers=None, upto: int = 12):
     masks, cs, labels = stage02(bgr, cfg, centers)
     res.update(masks=masks, centers=cs, labels=labels)
     if upto < 3: return res
-    res["edges"] = {n: stage03(masks[n], cfg) for n in names}
-    if upto < 4: return res
-    res["contours"] = {n: stage04(res["edges"][n]) for n in names}
-    if upto < 5: return res
-    res["scaled"] = {n: stage05(res["contours"][n], w, h, cfg) for n in names}
-    if upto < 7: return res
-    res["sorted"] = {n: sort07(res["scaled"][n]) for n in names}
-    if upto < 8: return res
     prm08 = derived08(cfg)
-    res["intra"] = {n: stage08_layer(res["sorted"][n], prm08) for n in names}
+
+    def front(n):
+        out = {"edges": stage03(masks[n], cfg)}
+        if upto >= 4: out["contours"] = stage04(out["edges"])
+        if upto >= 5: out["scaled"] = stage05(out["contours"], w, h, cfg)
+        if upto >= 7: out["sorted"] = sort07(out["scaled"])
+        if upto >= 8: out["intra"] = stage08_layer(out["sorted"], prm08)
+        return out
+
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            fronts = dict(zip(names, pool.map(front, names)))
+    else:
+        fronts = {n: front(n) for n in names}
+    for key in ("edges", "contours", "scaled", "sorted", "intra"):
+        if key in fronts[names[0]]:
+            res[key] = {n: fronts[n][key] for n in names}
     if upto < 10: return res
     res["cross"] = stage10(res["intra"], cfg)
     if upto < 12: return res
