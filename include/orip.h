@@ -122,6 +122,9 @@ int orip_dedup_cross_layer(orip_ctx* ctx, int layer);
 /* same, reading LINES/TAPS_INTRA of slot `src_layer` and writing LINES/TAPS_CROSS of `layer` (layer-sharded processes keep their
  * own layers under local indices and stage remote ones in a spare slot) */
 int orip_dedup_cross_layer_from(orip_ctx* ctx, int src_layer, int layer);
+/* same, but the travel reorder of the kept lines (10:253) is left to orip_plot_order(layer), which runs it first on the layer's own
+ * stream: LINES_CROSS of `layer` is in cut order until then (resident pipelines only; nothing else in stage 10 depends on that order) */
+int orip_dedup_cross_layer_deferred(orip_ctx* ctx, int src_layer, int layer);
 /* ---- stage 12: _build_ops_for_layer (12:85-187): LINES/TAPS_CROSS -> ops ----
  * ops are returned as 5 int32 each: (type 0 line / 1 tap, line index into LINES_CROSS, flip, x, y). */
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);

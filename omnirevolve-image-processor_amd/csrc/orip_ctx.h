@@ -101,6 +101,7 @@ struct orip_ctx {
     LaneRes ln[ORIP_MAX_LAYERS + 2];      // 0: raster stages; l + 1: layer l; ORIP_LANE_CROSS: stage 10
     std::atomic<int> lane_owner[ORIP_MAX_LAYERS + 2];   // 1 while a call holds the lane (LaneGuard); lane 0 is not claimed
     orip_params10 p10{}; bool p10_ready = false;   // stage 10 between orip_dedup_cross_begin and the per-layer calls
+    bool cross_unordered[ORIP_MAX_LAYERS] = {false};   // LINES_CROSS of the layer still waits for its travel reorder (orip_dedup_cross_layer_deferred)
     void* prep04 = nullptr;               // stage-04 state between orip_contours_prepare and orip_contours_layer (raster04.hip)
     std::mutex mu;
     std::string err;
@@ -115,6 +116,7 @@ struct orip_ctx {
     DBuf lab_tabs;  // u16 gamma[256] + u16 cbrt[3072] + i32 coeffs[9]
     bool tabs_ready = false;
     const void* edge_bits = nullptr;   // bit planes of `edges` left in lane 0's scratch by stage 03 (nullptr: not available); consumed by stage 04
+    const void* morphed_bits = nullptr; // bit planes of the opened / closed masks left in tmpA for stage 03's NMS kernel (nullptr: byte planes in tmpB)
     const void* mask_bits = nullptr;   // bit planes of `masks` left in tmpA by stage 02 (nullptr: not available); consumed by stage 03
     // vector state
     DPolys polys[ORIP_SLOT_COUNT][ORIP_MAX_LAYERS];

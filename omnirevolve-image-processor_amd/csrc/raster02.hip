@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256) void k_not_binary(const u8* __restrict__ src, 
 }
 
 // open (erode^n, dilate^n) then close (dilate^n, erode^n); src plane(s) -> dst plane(s); uses tmpA as ping-pong
-int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode) {
+// unpack == false: when the chain ran on bit planes, leave the result there (c->morphed_bits) and do not write the byte planes (stage 03)
+int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode, bool unpack = true) {
     if (k < 1 || k > 7 || (k & 1) == 0) ORIP_FAIL(c, "structuring element size %d unsupported (odd, 1..7)", k);
     int H = c->H, W = c->W; size_t plane = (size_t)H * W;
     unsigned long long se = make_se_bits(shape, k);
@@ -771,7 +772,8 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
             hipLaunchKernelGGL(k_morph_bits, gw, block, 0, LN(c).stream, A, B, H, W, Ww, k, se, passes[i] == 1 ? 1 : 0);
             std::swap(A, B);
         }
-        hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
+        if (unpack) hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
+        else c->morphed_bits = A;
         HIPC(c, hipGetLastError());
         if (labels_mode && dst == c->masks.as<u8>()) c->mask_bits = A;      // stage 03 can start from the bit planes
         return 0;

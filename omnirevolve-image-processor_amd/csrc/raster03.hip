@@ -7,7 +7,7 @@
 #include "orip_ctx.h"
 #include <algorithm>
 
-int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode);
+int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape, int k, int open_iters, int close_iters, bool labels_mode, bool unpack = true);
 
 // ------------------------------------------------------------------------------------------------
 // Gaussian (fixed tables) + Sobel + NMS.  Output map: 0 weak candidate, 1 not an edge,
@@ -106,6 +106,111 @@ __global__ __launch_bounds__(256) void k_blur_sobel_nms(const u8* __restrict__ m
                 const size_t w = (size_t)H * Ww * blockIdx.z + (size_t)y * Ww + (x0 >> 6);
                 cand_bits[w] = cm; strong_bits[w] = sm;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same for BINARY masks and the default 3x3 Gaussian, straight from the bit planes the morphology leaves (1 bit per pixel instead of a
+// byte plane written and read back: 2 x K x H x W bytes of HBM traffic less, and no per-byte border arithmetic).  With mask values {0, 255}
+// the blurred pixel is (255 c + 8) >> 4, c = the [1 2 1] x [1 2 1] weighted count of set pixels, i.e. a function of three 3-bit fields.
+// Tile 64 x 32 outputs; LDS: 38 rows x 3 words of mask bits around the tile (BORDER_REFLECT_101 already applied to them), the blurred
+// tile (halo 2, positions outside the image take the clamped position's value = Sobel's BORDER_REPLICATE), the magnitudes (halo 1).
+// ------------------------------------------------------------------------------------------------
+#define NB_TX 64
+#define NB_TY 32
+__global__ __launch_bounds__(256) void k_nms_bits3(const unsigned long long* __restrict__ mbits, int H, int W, int Ww, int low, int high,
+                                                   unsigned long long* __restrict__ cand_bits, unsigned long long* __restrict__ strong_bits) {
+    __shared__ unsigned long long R[NB_TY + 6][4];        // words x0/64 - 1 .. + 1 of rows y0 - 3 .. y0 + NB_TY + 2 (4th word: padding)
+    __shared__ u8 B[NB_TY + 4][NB_TX + 4];
+    __shared__ short MAG[NB_TY + 2][NB_TX + 2];
+    const int bx = blockIdx.x, x0 = bx * NB_TX, y0 = blockIdx.y * NB_TY;
+    const unsigned long long* src = mbits + (size_t)H * Ww * blockIdx.z;
+    const int tid = threadIdx.x;
+    // A tile whose whole neighbourhood (columns x0 - 3 .. x0 + 66 of the 38 rows) is uniformly 0 or uniformly 1 has a constant blurred
+    // value, no gradient and no candidate: most tiles of a mask made of large regions leave here after one pass over 114 words.
+    int mixed = 0;
+    if (tid < (NB_TY + 6) * 3) {
+        const int row = tid / 3, wj = tid % 3;
+        const int y = reflect101(y0 - 3 + row, H), xw = bx - 1 + wj;
+        const unsigned long long w = (xw >= 0 && xw < Ww) ? src[(size_t)y * Ww + xw] : 0ULL;
+        R[row][wj] = w;
+        // bits of this word that lie inside the image AND inside the neighbourhood
+        unsigned long long need = wj == 0 ? (7ULL << 61) : (wj == 1 ? ~0ULL : 7ULL);
+        if (xw < 0 || xw >= Ww) need = 0;
+        else if (xw == Ww - 1 && (W & 63)) need &= (1ULL << (W & 63)) - 1ULL;
+        const unsigned long long first = src[(size_t)reflect101(y0, H) * Ww + bx] & 1ULL ? ~0ULL : 0ULL;     // reference value: the tile's first pixel
+        mixed = ((w ^ first) & need) != 0;
+    }
+    if (!__syncthreads_or(mixed)) {
+        for (int ty = tid; ty < NB_TY; ty += 256) if (y0 + ty < H) { const size_t wd = (size_t)H * Ww * blockIdx.z + (size_t)(y0 + ty) * Ww + bx; cand_bits[wd] = 0ULL; strong_bits[wd] = 0ULL; }
+        return;
+    }
+    if (tid < NB_TY + 6) {                                // reflected columns: x = -1, -2, -3 and x = W, W + 1, W + 2 where the window holds them
+        auto getb = [&](int x) -> unsigned long long { const int p = x - (x0 - 64); return (R[tid][p >> 6] >> (p & 63)) & 1ULL; };
+        auto setb = [&](int x, unsigned long long b) { const int p = x - (x0 - 64); if (p >= 0 && p < 192) R[tid][p >> 6] = (R[tid][p >> 6] & ~(1ULL << (p & 63))) | (b << (p & 63)); };
+        if (bx == 0) for (int j = 1; j <= 3; j++) setb(-j, getb(j));
+        if (x0 + NB_TX + 3 > W) for (int j = 0; j < 3; j++) setb(W + j, getb(W - 2 - j));
+    }
+    __syncthreads();
+    // blurred tile with halo 2
+    for (int i = tid; i < (NB_TY + 4) * (NB_TX + 4); i += 256) {
+        const int ty = i / (NB_TX + 4), tx = i % (NB_TX + 4);
+        const int y = y0 + ty - 2, x = x0 + tx - 2;
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        const int r = yc - y0 + 3, p = xc - 1 - (x0 - 64);           // row of the centre in R; window bit of column xc - 1
+        const int wi = p >> 6, sh = p & 63;
+        auto field = [&](int rr) -> unsigned {
+            unsigned long long v = R[rr][wi] >> sh;
+            if (sh > 61) v |= R[rr][wi + 1] << (64 - sh);
+            return (unsigned)v & 7u;
+        };
+        const unsigned LUT = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (1u << 12) | (2u << 15) | (3u << 18) | (4u << 21);   // [1 2 1] . bits
+        const unsigned c9 = ((LUT >> (3 * field(r - 1))) & 7u) + 2u * ((LUT >> (3 * field(r))) & 7u) + ((LUT >> (3 * field(r + 1))) & 7u);
+        B[ty][tx] = (u8)((255u * c9 + 8u) >> 4);
+    }
+    __syncthreads();
+    for (int i = tid; i < (NB_TY + 2) * (NB_TX + 2); i += 256) {     // magnitude with halo 1 (0 outside the image)
+        const int ty = i / (NB_TX + 2), tx = i % (NB_TX + 2);
+        const int y = y0 + ty - 1, x = x0 + tx - 1;
+        int m = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const int by = ty + 1, bx2 = tx + 1;
+            const int gx = ((int)B[by - 1][bx2 + 1] + 2 * (int)B[by][bx2 + 1] + (int)B[by + 1][bx2 + 1]) - ((int)B[by - 1][bx2 - 1] + 2 * (int)B[by][bx2 - 1] + (int)B[by + 1][bx2 - 1]);
+            const int gy = ((int)B[by + 1][bx2 - 1] + 2 * (int)B[by + 1][bx2] + (int)B[by + 1][bx2 + 1]) - ((int)B[by - 1][bx2 - 1] + 2 * (int)B[by - 1][bx2] + (int)B[by - 1][bx2 + 1]);
+            m = abs(gx) + abs(gy);
+        }
+        MAG[ty][tx] = (short)m;
+    }
+    __syncthreads();
+    for (int i = tid; i < NB_TY * NB_TX; i += 256) {                  // a wave = one row of the tile
+        const int ty = i / NB_TX, tx = i % NB_TX;
+        const int y = y0 + ty, x = x0 + tx;
+        const bool in = y < H && x < W;
+        int res = 1;
+        if (in) {
+            const int by = ty + 2, bx2 = tx + 2;
+            const int xs = ((int)B[by - 1][bx2 + 1] + 2 * (int)B[by][bx2 + 1] + (int)B[by + 1][bx2 + 1]) - ((int)B[by - 1][bx2 - 1] + 2 * (int)B[by][bx2 - 1] + (int)B[by + 1][bx2 - 1]);
+            const int ys = ((int)B[by + 1][bx2 - 1] + 2 * (int)B[by + 1][bx2] + (int)B[by + 1][bx2 + 1]) - ((int)B[by - 1][bx2 - 1] + 2 * (int)B[by - 1][bx2] + (int)B[by - 1][bx2 + 1]);
+            const int my = ty + 1, mx = tx + 1;
+            const int m = MAG[my][mx];
+            if (m > low) {
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * 13573;
+                bool keep;
+                if (ay < tg22x) keep = (m > MAG[my][mx - 1] && m >= MAG[my][mx + 1]);
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = (m > MAG[my - 1][mx] && m >= MAG[my + 1][mx]);
+                    else { const int sg = ((xs ^ ys) < 0) ? -1 : 1; keep = (m > MAG[my - 1][mx - sg] && m > MAG[my + 1][mx + sg]); }
+                }
+                if (keep) res = (m > high) ? 2 : 0;
+            }
+        }
+        const unsigned long long cm = __ballot(in && res != 1), sm = __ballot(in && res == 2);
+        if ((tid & 63) == 0 && y < H) {
+            const size_t w = (size_t)H * Ww * blockIdx.z + (size_t)y * Ww + bx;
+            cand_bits[w] = cm; strong_bits[w] = sm;
         }
     }
 }
@@ -332,7 +437,10 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
     HIPC(c, c->edges.ensure(plane * K));
     HIPC(c, c->tmpB.ensure(plane * K));   // morphed masks
     HIPC(c, c->tmpC.ensure(plane * K));   // NMS map
-    ORIP_TRY(orip_morph_open_close(c, c->masks.as<u8>(), c->tmpB.as<u8>(), K, 2, morph_k, open_iters, close_iters, false));
+    // binary masks + 3x3 Gaussian: the NMS kernel reads the morphed bit planes, no byte plane in between
+    const bool nms_from_bits = gauss_k == 3 && W >= 8 && H >= 8 && !getenv("ORIP_CCL_BYTES") && !getenv("ORIP_NMS_BYTES");
+    c->morphed_bits = nullptr;
+    ORIP_TRY(orip_morph_open_close(c, c->masks.as<u8>(), c->tmpB.as<u8>(), K, 2, morph_k, open_iters, close_iters, false, !nms_from_bits));
     dim3 grid(cdiv(W, ET_X), cdiv(H, ET_Y), K), block(256);
     int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; size_t pplane = (size_t)Wb * Hb * 4;
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
@@ -346,7 +454,11 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
         HIPC(c, LN(c).vtmp[10].ensure(nw * K * 16 + 64));
         unsigned long long* cand = LN(c).vtmp[11].as<unsigned long long>(); unsigned long long* strong = cand + nw * K;
         unsigned long long* ebits = LN(c).vtmp[10].as<unsigned long long>();
-        { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), (u8*)nullptr, H, W, gauss_k, low, high, cand, strong, Ww); }
+        if (nms_from_bits && c->morphed_bits) {
+            ProfScope ps(c, "k_blur_sobel_nms");
+            hipLaunchKernelGGL(k_nms_bits3, dim3(cdiv(W, NB_TX), cdiv(H, NB_TY), K), block, 0, LN(c).stream, (const unsigned long long*)c->morphed_bits, H, W, Ww, low, high, cand, strong);
+        } else { ProfScope ps(c, "k_blur_sobel_nms"); hipLaunchKernelGGL(k_blur_sobel_nms, grid, block, 0, LN(c).stream, c->tmpB.as<u8>(), (u8*)nullptr, H, W, gauss_k, low, high, cand, strong, Ww); }
+        c->morphed_bits = nullptr;
         ORIP_TRY(orip_ccl_bits(c, cand, c->tmpD.as<int>(), K));
         HIPC(c, hipMemsetAsync(LN(c).tmpE.p, 0, pplane * K, LN(c).stream));
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);

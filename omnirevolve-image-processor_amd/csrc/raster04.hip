@@ -135,9 +135,13 @@ __global__ __launch_bounds__(64) void k_trace(WalkArgs A) {
     if (i >= A.nc) return;
     trace_component(A, A.comp_order ? A.comp_order[i] : i);
 }
-// one wavefront per kept walk
-__global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, const unsigned* __restrict__ kept_slots, unsigned n_kept) {
-    for (unsigned i = blockIdx.x; i < n_kept; i += gridDim.x) write_walk(A, kept_slots[i]);
+// one wavefront per chunk of `chunk` output points
+__global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, int layer, const unsigned* __restrict__ kept_slots, const unsigned long long* __restrict__ kept_off, unsigned n_kept,
+                                                    unsigned long long total, unsigned chunk) {
+    for (unsigned long long ci = blockIdx.x; ci * chunk < total; ci += gridDim.x) {
+        const unsigned long long p0 = ci * chunk, p1 = p0 + chunk < total ? p0 + chunk : total;
+        write_chunk(A, layer, kept_slots, kept_off, n_kept, p0, p1);
+    }
 }
 // lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here
 __global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
@@ -272,9 +276,10 @@ __global__ __launch_bounds__(256) void k_clear_visited_layer(u8* __restrict__ st
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < m) st[lin[i]] &= (u8)~ST_VIS;
 }
-__global__ __launch_bounds__(256) void k_kept_slots_base(const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off, unsigned n, unsigned base, unsigned* __restrict__ slots) {
+__global__ __launch_bounds__(256) void k_kept_slots_base(const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off, const unsigned long long* __restrict__ pts_off, unsigned n, unsigned base,
+                                                         unsigned* __restrict__ slots, unsigned long long* __restrict__ slot_off) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && kept[i]) slots[path_off[i]] = base + i;
+    if (i < n && kept[i]) { slots[path_off[i]] = base + i; slot_off[path_off[i]] = pts_off[i]; }
 }
 
 // Everything of stage 04 that is batched over the layers: thinning, components, state bytes, the raster-ordered pixel list
@@ -482,9 +487,9 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     }
     // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
     const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
-    HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
-    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1);
-    unsigned* kept = (unsigned*)(pts_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
+    HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
+    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1); unsigned long long* kept_off = pts_off + (nslots + 1);
+    unsigned* kept = (unsigned*)(kept_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
     {
         WalkArgs A = R.A;                    // the layer's logs as the trace addressed them (walk_close_tail follows the recorded trajectories)
         A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)R.F[layer] * b0 + (size_t)64 * c0);
@@ -510,9 +515,10 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
         A.pts_off = pts_off - sl0; A.path_off = path_off - sl0;          // indexed by global slot
         A.layer_pts_base[layer] = 0; A.layer_path_base[layer] = 0;
         A.pts[layer] = P.pts.as<int32_t>(); A.off[layer] = P.off.as<int64_t>();
-        hipLaunchKernelGGL(k_kept_slots_base, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, nslots, sl0, kept_slots);
+        hipLaunchKernelGGL(k_kept_slots_base, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, pts_off, nslots, sl0, kept_slots, kept_off);
         ProfScope ps(c, "k_write_walks");
-        hipLaunchKernelGGL(k_write_walks, dim3(std::min(h_paths, 262144u)), dim3(64), 0, LN(c).stream, A, kept_slots, h_paths);
+        const unsigned chunk = 4096;
+        hipLaunchKernelGGL(k_write_walks, dim3((unsigned)std::min<unsigned long long>((h_pts + chunk - 1) / chunk, 262144ull)), dim3(64), 0, LN(c).stream, A, layer, kept_slots, kept_off, h_paths, h_pts, chunk);
     }
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(LN(c).stream));

@@ -264,6 +264,12 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     ORIP_LANE(c, layer + 1);
     DPolys& L = c->polys[ORIP_SLOT_LINES_CROSS][layer]; DTaps& T = c->taps[ORIP_TAPS_CROSS][layer];
+    if (c->cross_unordered[layer]) {                 // stage 10's travel reorder (10:253), deferred to this lane by orip_dedup_cross_layer_deferred
+        DPolys& tmp = LN(c).tp[5];
+        ORIP_TRY(vreorder(c, L, tmp, 10));
+        std::swap(tmp.off, L.off); std::swap(tmp.pts, L.pts); L.n = tmp.n; L.total = tmp.total;
+        c->cross_unordered[layer] = false;
+    }
     int64_t nl = L.n, nt = T.n;
     c->n_ops[layer] = 0; *n_ops = 0;
     if (nl + nt == 0) return 0;

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(64) void k_tiny_taps10(const int64_t* __restrict__ 
         const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;
         unsigned tap = 0, keep = 0; int2 txy = make_int2(0, 0);
         double big = fmax(P.tap_diam, P.min_keep) + 2.0;
-        if ((double)max(x1 - x0, y1 - y0) > big) keep = 1;      // enclosing diameter >= bbox extent > both thresholds: no circle needed
+        const double ext = (double)max(x1 - x0, y1 - y0);
+        if (ext > big) keep = 1;                                 // enclosing diameter >= bbox extent > both thresholds: no circle needed
+        else if (n > (int64_t)P.tap_max_v && ext >= P.min_keep + 2.0) keep = 1;     // too many vertices for a tap (10:108-112) and certainly not tiny: no circle either
         else {
             float cx, cy, r; mec_wave(p, (int)n, cx, cy, r, lane);
             double d = 2.0 * (double)r;
@@ -380,8 +382,15 @@ extern "C" int orip_dedup_cross_begin(orip_ctx* c, const orip_params10* prm) {
 
 // input lists from layer slot `src_layer` (LINES/TAPS_INTRA), output and reporting under `layer`: lets a process that holds its own
 // layers under local indices feed stage 10 in global layer order (multi-GPU layer sharding)
+static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool reorder_now);
 extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer) {
-    orip_enter(c);
+    orip_enter(c); return dedup_cross_layer_impl(c, src_layer, layer, true); }
+// The same without the travel reorder of the kept lines (10:253, _reorder_for_travel): nothing later in stage 10 depends on their order
+// (the paint is a union, the taps keep their own order), so the one-wave greedy chain need not sit on the serial layer-after-layer path of
+// this stage.  LINES_CROSS of `layer` is left in cut order and marked; orip_plot_order(layer) reorders it first, on the layer's own lane.
+extern "C" int orip_dedup_cross_layer_deferred(orip_ctx* c, int src_layer, int layer) {
+    orip_enter(c); return dedup_cross_layer_impl(c, src_layer, layer, false); }
+static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool reorder_now) {
     if (src_layer < 0 || src_layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", src_layer);
     if (!c->p10_ready) ORIP_FAIL(c, "orip_dedup_cross_begin has not run");
     const orip_params10 P = c->p10;
@@ -452,8 +461,13 @@ extern "C" int orip_dedup_cross_layer_from(orip_ctx* c, int src_layer, int layer
         if (Tin.n) HIPC(c, hipMemcpyAsync(seq, Tin.xy.p, (size_t)Tin.n * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         if (n_tap_lines) hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, LN(c).stream, is_tap, tap_scan, cut.n, cut.off.as<int64_t>(), (GatherDesc*)nullptr, tap_xy, seq + Tin.n);
         auto t2 = tdbg ? now() : t0;
-        // ---- 4) reorder
-        ORIP_TRY(vreorder(c, keepl, Lout, 10));
+        // ---- 4) reorder (or hand the kept lines over as they are: orip_dedup_cross_layer_deferred)
+        if (reorder_now) { ORIP_TRY(vreorder(c, keepl, Lout, 10)); c->cross_unordered[layer] = false; }
+        else {
+            if (keepl.n == 0) { HIPC(c, keepl.off.ensure(64)); HIPC(c, hipMemsetAsync(keepl.off.p, 0, 8, LN(c).stream)); }
+            std::swap(keepl.off, Lout.off); std::swap(keepl.pts, Lout.pts); Lout.n = keepl.n; Lout.total = keepl.total;
+            c->cross_unordered[layer] = true;
+        }
         auto t3 = tdbg ? now() : t0;
         // ---- 5) paint lines (exact disc dilation of all vertices)
         if (Lout.total > 0) {

@@ -11,8 +11,9 @@
 //     so a trajectory recorded once stays valid.  No-fresh states are logged (state log) and indexed (memo); reaching a state
 //     of the walk's own current run closes a cycle exactly (no Brent overhead), reaching a committed state of an earlier walk
 //     means "the rest is that trajectory".  Either way the guard-bounded tail (up to 4*fg+1 points) is not walked.
-// write_walk: one wavefront per recorded walk turns the record into points: a wave prefix sum over the direction codes for the
-// walk's own steps, and an indexed copy out of the state log for the tail.  No second serial pass, no visited state.
+// write_chunk: the point array of a layer is cut into equal chunks, one wavefront each; a chunk turns the records of the walks it covers
+// into points: a wave prefix sum over the direction codes for a walk's own steps, an indexed copy out of the state log for its tail.
+// No second serial pass, no visited state.
 //
 // The same source is compiled with g++ by tests/host/walk_harness.cpp, where a "wave" is emulated by plain loops, so the walk
 // logic (phases, guards, memo, cycle closing) is unit-tested on the CPU as well (test infrastructure).
@@ -710,60 +711,90 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     }
 }
 
-// Points of one recorded walk (winfo slot `slot`), written by one wavefront.
-ORIP_HD inline void write_walk(const WalkArgs& A, unsigned slot) {
+// Points [p0, p1) of a layer's contour list (positions in the concatenated point array of its kept walks), written by one wavefront.
+// The output is cut into equal chunks instead of giving one wave to each walk: a few walks carry millions of points (bounce tails up to
+// the guard), and one wave writing such a walk alone was the whole duration of the pass.  kept[i] = walk slot of path i, in output order,
+// kept_off[i] = index of its first point.
+ORIP_HD inline void write_chunk(const WalkArgs& A, int layer, const unsigned* kept, const unsigned long long* kept_off, unsigned n_kept, unsigned long long p0, unsigned long long p1) {
     using namespace walk_detail;
-    const WalkInfo wi = A.winfo[slot];
-    if (!wi.len_kept) return;
     Wave wv;
-    // component of the slot: slots [2b, 2e) belong to the component whose list range is [b, e)
-    unsigned lo = 0, hi = A.nc;
-    while (lo < hi) { unsigned mid = (lo + hi) >> 1; if (2u * A.comp_start[mid + 1] <= slot) lo = mid + 1; else hi = mid; }
-    const unsigned c = lo, b = A.comp_start[c], fg = A.comp_start[c + 1] - b;
-    const unsigned rel = slot - 2u * b;
-    const unsigned q = b + (rel >= fg ? rel - fg : rel);
-    const int layer = (int)(A.keys[b] >> 26);
     const int W = A.W;
-    const unsigned s = A.lin[q];
-    const int x0 = (int)(s % (unsigned)W), y0 = (int)(s / (unsigned)W);
-    int2* out = reinterpret_cast<int2*>(A.pts[layer]) + (A.pts_off[slot] - A.layer_pts_base[layer]);
-    if (wv.leader()) {
-        out[0] = make_int2(x0, y0);
-        A.off[layer][A.path_off[slot] - A.layer_path_base[layer] + 1] = (int64_t)(A.pts_off[slot] - A.layer_pts_base[layer] + wi.len_kept);
-        if (wi.flags & 1u) out[wi.len_kept - 1] = make_int2(x0, y0);
-    }
-    // own steps: prefix sums of the direction vectors
-    int cx = x0, cy = y0;
-    for (unsigned base = 0; base < wi.n_own; base += wv.nl()) {
-        unsigned t = base + wv.l0();
-        int dx = 0, dy = 0;
-        if (t < wi.n_own) { int k = A.steplog[(size_t)wi.step_begin + t]; dx = nbx(k); dy = nby(k); }
-        int ox, oy, tx, ty;
-        wv.scan2(dx, dy, ox, oy, tx, ty);
-        if (t < wi.n_own) out[1 + t] = make_int2(cx + ox, cy + oy);
-        cx += tx; cy += ty;
-    }
-    // tail: recorded trajectory, entry i+1+j, wrapping from `end` to `cyc_begin`
-    if (wi.log_i1) {
-        // the tail is the trajectory after entry i: a chain of record pieces (rest of i's record, then the records it continues
-        // into) that ends in a cycle.  The chain is walked once per wave; each piece is a contiguous run of log entries.
-        const unsigned i = wi.log_i1 - 1;
-        int2* o2 = out + 1 + wi.n_own;
-        unsigned long long done = 0, f0 = (unsigned long long)i + 1; unsigned rec = i;
-        while (done < wi.R) {
-            const unsigned cont = A.logbuf[4ull * rec + 1], en = A.logbuf[4ull * rec + 2], begin = A.logbuf[4ull * rec + 3];
-            if (f0 < en) {
-                unsigned long long take = en - f0; if (take > wi.R - done) take = wi.R - done;
-                for (unsigned long long j = wv.l0(); j < take; j += wv.nl()) { unsigned l = A.logbuf[4ull * (f0 + j)] >> 3; o2[done + j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W)); }
-                done += take;
-                if (done >= wi.R) break;
+    int2* outp = reinterpret_cast<int2*>(A.pts[layer]);
+    // path holding point p0: the last i with start(i) <= p0
+    unsigned lo = 0, hi = n_kept;
+    while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (kept_off[mid] <= p0) lo = mid; else hi = mid; }
+    for (unsigned i = lo; i < n_kept; i++) {
+        const unsigned slot = kept[i];
+        const unsigned long long ws = kept_off[i];
+        if (ws >= p1) break;
+        const WalkInfo wi = A.winfo[slot];
+        const unsigned long long L = wi.len_kept;
+        const unsigned long long ta = (p0 > ws ? p0 : ws) - ws, tb = (p1 < ws + L ? p1 : ws + L) - ws;      // this walk's points [ta, tb)
+        if (ta >= tb) continue;
+        int2* out = outp + ws;
+        // start pixel of the walk: slots [2b, 2e) belong to the component whose list range is [b, e)
+        unsigned clo = 0, chi = A.nc;
+        while (clo < chi) { unsigned mid = (clo + chi) >> 1; if (2u * A.comp_start[mid + 1] <= slot) clo = mid + 1; else chi = mid; }
+        const unsigned b = A.comp_start[clo], fg = A.comp_start[clo + 1] - b, rel = slot - 2u * b;
+        const unsigned s = A.lin[b + (rel >= fg ? rel - fg : rel)];
+        const int x0 = (int)(s % (unsigned)W), y0 = (int)(s / (unsigned)W);
+        if (wv.leader()) {
+            if (ta == 0) { out[0] = make_int2(x0, y0); A.off[layer][i + 1] = (int64_t)(ws + L); }
+            if ((wi.flags & 1u) && tb == L) out[L - 1] = make_int2(x0, y0);
+        }
+        // ---- own steps: point t (1 <= t <= n_own) = start + sum of the direction vectors of codes [0, t)
+        const unsigned long long own_a = ta > 1 ? ta : 1, own_b = tb < (unsigned long long)wi.n_own + 1 ? tb : (unsigned long long)wi.n_own + 1;
+        if (own_a < own_b) {
+            int cx = x0, cy = y0;
+            for (unsigned long long c0 = 0; c0 < own_a - 1; c0 += wv.nl()) {            // codes before the chunk: only their sum
+                const unsigned long long t = c0 + wv.l0();
+                int dx = 0, dy = 0;
+                if (t < own_a - 1) { const int k = A.steplog[(size_t)wi.step_begin + t]; dx = nbx(k); dy = nby(k); }
+                int ox, oy, tx, ty; wv.scan2(dx, dy, ox, oy, tx, ty);
+                cx += tx; cy += ty;
             }
-            if (cont >= begin) {           // cycle [cont, en): the rest of the tail
-                const unsigned long long lam = en - cont, rest = wi.R - done;
-                for (unsigned long long j = wv.l0(); j < rest; j += wv.nl()) { unsigned l = A.logbuf[4ull * (cont + j % lam)] >> 3; o2[done + j] = make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W)); }
-                break;
+            for (unsigned long long t0 = own_a; t0 < own_b; t0 += wv.nl()) {
+                const unsigned long long t = t0 + wv.l0();
+                int dx = 0, dy = 0;
+                if (t < own_b) { const int k = A.steplog[(size_t)wi.step_begin + t - 1]; dx = nbx(k); dy = nby(k); }
+                int ox, oy, tx, ty; wv.scan2(dx, dy, ox, oy, tx, ty);
+                if (t < own_b) out[t] = make_int2(cx + ox, cy + oy);
+                cx += tx; cy += ty;
             }
-            f0 = cont; rec = cont;         // transient record exhausted: continue in the older record
+        }
+        // ---- tail: tail point u (0 <= u < R) is entry i + 1 + u of the recorded trajectory, which is a chain of record pieces ending in a cycle
+        if (wi.log_i1) {
+            const unsigned long long tail0 = (unsigned long long)wi.n_own + 1;
+            unsigned long long ua = (ta > tail0 ? ta : tail0) - tail0, ub = (tb < tail0 + wi.R ? tb : tail0 + wi.R);
+            if (ub > tail0 && ua < ub - tail0) {
+                ub -= tail0;
+                int2* o2 = out + tail0;
+                unsigned long long done = 0, f0 = (unsigned long long)(wi.log_i1 - 1) + 1; unsigned rec = wi.log_i1 - 1;
+                const bool pow2 = (W & (W - 1)) == 0; const int wsh = pow2 ? __builtin_ctz((unsigned)W) : 0;      // x = l % W, y = l / W without a division where W allows
+                auto put = [&](unsigned long long u, unsigned long long entry) {
+                    const unsigned l = A.logbuf[4ull * entry] >> 3;
+                    o2[u] = pow2 ? make_int2((int)(l & (unsigned)(W - 1)), (int)(l >> wsh)) : make_int2((int)(l % (unsigned)W), (int)(l / (unsigned)W));
+                };
+                while (done < ub) {
+                    const unsigned cont = A.logbuf[4ull * rec + 1], en = A.logbuf[4ull * rec + 2], begin = A.logbuf[4ull * rec + 3];
+                    if (f0 < en) {                               // the rest of this record: tail points [done, done + take)
+                        const unsigned long long take = en - f0;
+                        const unsigned long long a = ua > done ? ua : done, bnd = ub < done + take ? ub : done + take;
+                        for (unsigned long long u = a + wv.l0(); u < bnd; u += wv.nl()) put(u, f0 + (u - done));
+                        done += take;
+                        if (done >= ub) break;
+                    }
+                    if (cont >= begin) {                         // cycle [cont, en): everything that is left
+                        const unsigned lam = en - cont;
+                        const unsigned long long a = ua > done ? ua : done;
+                        unsigned ph = (unsigned)((a - done) % lam);                         // phase of point a inside the cycle (once per chunk)
+                        unsigned mine = (ph + wv.l0()) % lam; const unsigned stride = wv.nl() % lam;
+                        for (unsigned long long u = a + wv.l0(); u < ub; u += wv.nl()) { put(u, (unsigned long long)cont + mine); mine += stride; if (mine >= lam) mine -= lam; }
+                        break;
+                    }
+                    f0 = cont; rec = cont;                       // transient record exhausted: continue in the older record
+                }
+            }
         }
     }
 }

@@ -203,11 +203,13 @@ class Device:
     def dedup_cross_begin(self, prm: _l.Params10):
         self._ck(self.L.orip_dedup_cross_begin(self.h, C.byref(prm)))
 
-    def dedup_cross_layer(self, layer: int, src_layer: int | None = None):
-        if src_layer is None:
-            self._ck(self.L.orip_dedup_cross_layer(self.h, layer))
+    def dedup_cross_layer(self, layer: int, src_layer: int | None = None, defer_reorder: bool = False):
+        """defer_reorder: leave the travel reorder of the layer's lines (10:253) to plot_order(layer) -- resident pipelines only"""
+        src = layer if src_layer is None else src_layer
+        if defer_reorder:
+            self._ck(self.L.orip_dedup_cross_layer_deferred(self.h, src, layer))
         else:
-            self._ck(self.L.orip_dedup_cross_layer_from(self.h, src_layer, layer))
+            self._ck(self.L.orip_dedup_cross_layer_from(self.h, src, layer))
 
     # ---- multi-GPU exchange (RCCL inside liborip.so)
     def comm_unique_id(self) -> bytes:

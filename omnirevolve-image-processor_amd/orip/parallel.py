@@ -217,7 +217,7 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
             comm.bcast(owner, i, True)
             if failed:
                 continue
-            dev.dedup_cross_layer(i, src_layer=i)
+            dev.dedup_cross_layer(i, src_layer=i, defer_reorder=True)      # tail(): plot_order reorders the lines first, on lane i + 1
             tails.append(pool.submit(tail, i))
         else:
             comm.bcast(owner, stage_slot, False)

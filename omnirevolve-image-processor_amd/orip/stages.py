@@ -287,7 +287,7 @@ def run_layer_pipelines(d: Device, cfg: Config, W: int, H: int, layers, order, u
         if errors:
             for e in ready.values(): e.wait()
             raise errors[0]
-        d.dedup_cross_layer(l)
+        d.dedup_cross_layer(l, defer_reorder=tail is not None and l in ready)      # the tail (stage 12) reorders on the layer's own lane
         if tail is not None and l in ready:
             tails[l] = pool.submit(tail, l)
     return {l: f.result() for l, f in tails.items()}

@@ -62,6 +62,9 @@ extern "C" int walk_harness(const uint8_t* skel, int H, int W, int64_t* off_out,
     *n_paths = path_off[nslots]; *n_pts = (int64_t)pts_off[nslots];
     if (*n_paths + 1 > off_cap || *n_pts > pts_cap) return 1;
     A.pts_off = pts_off.data(); A.path_off = path_off.data(); A.pts[0] = pts_out; A.off[0] = off_out;
-    for (unsigned i = 0; i < nslots; i++) write_walk(A, i);
+    std::vector<unsigned> kept; std::vector<unsigned long long> kept_off;
+    for (unsigned i = 0; i < nslots; i++) if (winfo[i].len_kept) { kept.push_back(i); kept_off.push_back(pts_off[i]); }
+    const unsigned long long total = pts_off[nslots], chunk = 1000;       // the write pass in chunks, as k_write_walks cuts it (odd size: chunks start inside walks)
+    for (unsigned long long p0 = 0; p0 < total; p0 += chunk) write_chunk(A, 0, kept.data(), kept_off.data(), (unsigned)kept.size(), p0, std::min(total, p0 + chunk));
     return 0;
 }
