@@ -130,6 +130,13 @@ int orip_dedup_cross_layer_deferred(orip_ctx* ctx, int src_layer, int layer);
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);
 int orip_get_ops(orip_ctx* ctx, int layer, int32_t* ops5);
 
+/* ---- after the path: 13_build_stream.py ----
+ * Direction codes of n moves (x0, y0, x1, y1 in plotter steps), the helper's bresenham_dir_codes (shared/omnirevolve_plotter_stream_creator_helper.py
+ * :183-207) for all pen-up travels and polyline segments of a plot at once: codes 0 +Y, 1 NE, 2 +X, 3 SE, 4 -Y, 5 SW, 6 -X, 7 NW, concatenated in
+ * move order.  Two-call pattern: orip_stream_codes leaves them resident and returns the total, the fetch copies off[n+1] and codes[total]. */
+int orip_stream_codes(orip_ctx* ctx, const int32_t* moves /* [n,4] */, int64_t n, int64_t* total_steps);
+int orip_stream_codes_fetch(orip_ctx* ctx, int64_t* off_out /* [n+1] */, uint8_t* codes_out /* [total] */);
+
 /* ---- multi-GPU exchange (no counterpart in the reference, which is a single process) ----
  * One process per GPU; rank r owns the cluster layers {l : l % world == r} for stages 03-08 and 12.  Stage 10 is replicated and needs
  * every layer's stage-08 lists (10:236-267): orip_bcast_layer sends LINES_INTRA / TAPS_INTRA of one layer from its owner to all ranks

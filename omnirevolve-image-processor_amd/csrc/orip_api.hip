@@ -56,6 +56,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     orip_contours_free(c);
     orip_comm_destroy(c);
     c->comm_sizes.release();
+    c->stream_segs.release(); c->stream_off.release(); c->stream_codes.release();
     delete c;
 }
 

@@ -126,6 +126,8 @@ struct orip_ctx {
     // multi-GPU exchange (comm.hip): RCCL communicator of this process, device row for the list sizes
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     DBuf comm_sizes;
+    // 13_build_stream: moves and their direction codes (stream.hip), resident between orip_stream_codes and the fetch
+    DBuf stream_segs, stream_off, stream_codes; int64_t stream_n = 0, stream_total = 0;
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;

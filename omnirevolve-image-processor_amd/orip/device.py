@@ -211,6 +211,17 @@ class Device:
         else:
             self._ck(self.L.orip_dedup_cross_layer_from(self.h, src, layer))
 
+    # ---- 13_build_stream: direction codes of all moves of a plot
+    def stream_codes(self, moves: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """moves int32 [n,4] (x0, y0, x1, y1) -> (off int64 [n+1], codes uint8 [total])"""
+        m = np.ascontiguousarray(moves, np.int32).reshape(-1, 4)
+        total = C.c_int64(0)
+        self._ck(self.L.orip_stream_codes(self.h, _p(m) if len(m) else None, len(m), C.byref(total)))
+        off = np.zeros(len(m) + 1, np.int64)
+        codes = np.zeros(max(total.value, 1), np.uint8)
+        self._ck(self.L.orip_stream_codes_fetch(self.h, _p(off), _p(codes)))
+        return off, codes[:total.value]
+
     # ---- multi-GPU exchange (RCCL inside liborip.so)
     def comm_unique_id(self) -> bytes:
         buf = (C.c_uint8 * _l.COMM_ID_BYTES)()
