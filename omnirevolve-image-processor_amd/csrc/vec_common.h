@@ -564,6 +564,157 @@ __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restri
     e[i] = q;
 }
 
+// The same search with a step written for the way a lone wave executes (one instruction per ~4.5 cycles, +16..20 cycles whenever the scalar
+// unit consumes a value produced by a vector instruction, every exec-mask juggle of divergent control flow a handful of both):
+// k_greedy_nn_grid's step compiles to ~350 instructions with divergent loops around uniform values = 1.1 us per step.  Here
+//   * everything that is the same in all lanes (cursor, window, cell ranges, winner) is kept in SGPRs explicitly (v_readfirstlane);
+//   * the candidates of the 3x3 window are evaluated without branches: every lane maps its ordinal to an entry with selects, entries
+//     beyond the end take the pattern 0xffffffff; a candidate is a 2-byte entry + one 8-byte LDS read (both end points packed);
+//   * the minimum runs over the 32-bit float pattern of the squared distance (6 DPP steps); the index tie-break of the reference (first
+//     polyline in list order wins) only runs when two lanes hold the same pattern; the winner's end points come out of the winning lane's
+//     registers (v_readlane), not from another LDS round trip;
+//   * "no unscanned cell can be nearer" is an integer test: floor(d2) + 1 <= gap^2 - gap^2 / 2^18 - 1 (the three float roundings of a
+//     squared distance stay below 2^-22 relative): conservative, so at worst one more round is scanned, never a wrong winner;
+//   * results leave through a VGPR (one lane per step, 64 at a time).
+__global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2* P = reinterpret_cast<uint2*>(smem);                                     // .x = sx | sy << 16, .y = ex | ey << 16; bit 15 of sx: used, bit 15 of sy: closed (rule07)
+    unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // cst[0] = 0, cst[c + 1] = end of cell c
+    uint16_t* Eid = reinterpret_cast<uint16_t*>(cst + (G * G + 2));                // entries sorted by cell: idx << 1 | end
+    const int lane = threadIdx.x;
+#define NNU(x) __builtin_amdgcn_readfirstlane((int)(x))
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -0x7fffffff, mxy = -0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        NNEnds e = ends[i];
+        mnx = min(mnx, min(e.sx, e.ex)); mxx = max(mxx, max(e.sx, e.ex)); mny = min(mny, min(e.sy, e.ey)); mxy = max(mxy, max(e.sy, e.ey));
+    }
+    for (int o = 32; o > 0; o >>= 1) { mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64)); }
+    const int ox = mnx, oy = mny;
+    for (int i = lane; i < n; i += 64) {
+        NNEnds e = ends[i];
+        P[i] = make_uint2((unsigned)((e.sx - ox) | (i == seed ? 0x8000 : 0)) | ((unsigned)((e.sy - oy) | ((rule07 && e.closed) ? 0x8000 : 0)) << 16),
+                          (unsigned)(e.ex - ox) | ((unsigned)(e.ey - oy) << 16));
+    }
+    unsigned* cnt = cst + 1;                                                       // counts, then cell ends
+    for (int i = lane; i <= G * G + 1; i += 64) cst[i] = 0;
+    __syncthreads();
+    int sh = 0; while (((max(mxx - mnx, mxy - mny)) >> sh) >= G) sh++;
+    sh = NNU(sh);
+    for (int i = lane; i < n; i += 64) {
+        const uint2 e = P[i];
+        atomicAdd(&cnt[(((e.x >> 16) & 0x7fff) >> sh) * G + ((e.x & 0x7fff) >> sh)], 1u);
+        if (!(e.x & 0x80000000u)) atomicAdd(&cnt[((e.y >> 16) >> sh) * G + ((e.y & 0xffff) >> sh)], 1u);
+    }
+    __syncthreads();
+    {
+        const int per = (G * G + 63) / 64, c0 = lane * per, c1 = min(G * G, c0 + per);
+        unsigned sm = 0;
+        for (int cc = c0; cc < c1; cc++) sm += cnt[cc];
+        unsigned inc = sm;
+        for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        unsigned run = inc - sm;
+        for (int cc = c0; cc < c1; cc++) { unsigned v = cnt[cc]; cnt[cc] = run; run += v; }     // starts for now
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {         // scatter; cnt[c] ends up as the END of cell c, so start(c) = cst[c], end(c) = cst[c + 1]
+        const uint2 e = P[i];
+        Eid[atomicAdd(&cnt[(((e.x >> 16) & 0x7fff) >> sh) * G + ((e.x & 0x7fff) >> sh)], 1u)] = (uint16_t)(i << 1);
+        if (!(e.x & 0x80000000u)) Eid[atomicAdd(&cnt[((e.y >> 16) >> sh) * G + ((e.y & 0xffff) >> sh)], 1u)] = (uint16_t)((i << 1) | 1);
+    }
+    __syncthreads();
+    const unsigned n_ent = (unsigned)NNU(cst[G * G]);
+    int cx, cy;
+    { const uint2 e = P[seed]; const bool cl = (e.x & 0x80000000u) != 0; cx = NNU(cl ? (e.x & 0x7fff) : (e.y & 0xffff)); cy = NNU(cl ? ((e.x >> 16) & 0x7fff) : (e.y >> 16)); }
+    unsigned ringv = lane == 0 ? (unsigned)(seed << 1) : 0u;                      // lane (step & 63): index << 1 | flip of that step
+    const int Gm1 = G - 1;
+    for (int step = 1; step < n; step++) {
+        const int gx = cx >> sh, gy = cy >> sh;
+        const float fx = (float)cx, fy = (float)cy;
+        unsigned wi = 0, w0 = 0, w1 = 0;
+        for (int r = 1;; r = 2 * r + 1) {
+            const int x0 = max(0, gx - r), x1 = min(Gm1, gx + r), y0 = max(0, gy - r), y1 = min(Gm1, gy + r);
+            unsigned myk = ~0u, myi = 0x7fffffffu, my0 = 0, my1 = 0;
+            // entry `q` (clamped into the table) as a candidate; valid == false: counts as infinitely far
+            auto consider = [&](unsigned q, bool valid) {
+                const unsigned id = Eid[q < n_ent ? q : n_ent - 1u]; const unsigned i = id >> 1;
+                const uint2 e = P[i];
+                const unsigned xy = (id & 1u) ? e.y : (e.x & 0x7fff7fffu);
+                const float dx = __fsub_rn((float)(xy & 0xffffu), fx), dy = __fsub_rn((float)(xy >> 16), fy);
+                unsigned k = __float_as_uint(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                k = (valid && !(e.x & 0x8000u)) ? k : ~0u;                           // used polylines (the previous one among them) do not count
+                const unsigned long long key = ((unsigned long long)k << 32) | i, mine = ((unsigned long long)myk << 32) | myi;
+                const bool better = key < mine;
+                myk = better ? k : myk; myi = better ? i : myi; my0 = better ? e.x : my0; my1 = better ? e.y : my1;
+            };
+            if (y1 - y0 <= 2) {
+                // lanes 0..5: start / end of the entry range of the (up to) three rows
+                const int row = y0 + (lane >> 1);
+                const int ci = row * G + ((lane & 1) ? x1 + 1 : x0);
+                const unsigned bnd = (lane < 6 && row <= y1) ? cst[ci] : 0u;
+                const unsigned lo0 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 0), n0 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 1) - lo0;
+                const unsigned lo1 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 2), n1 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 3) - lo1;
+                const unsigned lo2 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 4), n2 = (unsigned)__builtin_amdgcn_readlane((int)bnd, 5) - lo2;
+                const unsigned n01 = n0 + n1, total = n01 + n2;
+                for (unsigned t0 = 0; t0 < total; t0 += 64) {                        // uniform trip count, no exec masking
+                    const unsigned t = t0 + lane;
+                    unsigned q = lo0 + t;
+                    q = t >= n0 ? lo1 + (t - n0) : q;
+                    q = t >= n01 ? lo2 + (t - n01) : q;
+                    consider(q, t < total);
+                }
+            } else {
+                for (int row = y0; row <= y1; row++) {
+                    const unsigned lo = (unsigned)NNU(cst[row * G + x0]), hi = (unsigned)NNU(cst[row * G + x1 + 1]);
+                    for (unsigned q0 = lo; q0 < hi; q0 += 64) consider(q0 + lane, q0 + lane < hi);
+                }
+            }
+            // minimum distance pattern over the wave
+            unsigned m = myk;
+#define ORIP_DPP_MINU(ctrl, rmask) { const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)m, ctrl, rmask, 0xf, false); m = t_ < m ? t_ : m; }
+            ORIP_DPP_MINU(0x111, 0xf) ORIP_DPP_MINU(0x112, 0xf) ORIP_DPP_MINU(0x114, 0xf) ORIP_DPP_MINU(0x118, 0xf) ORIP_DPP_MINU(0x142, 0xa) ORIP_DPP_MINU(0x143, 0xc)
+#undef ORIP_DPP_MINU
+            const unsigned mink = (unsigned)__builtin_amdgcn_readlane((int)m, 63);
+            bool final_ = x0 == 0 && y0 == 0 && x1 == Gm1 && y1 == Gm1;            // everything scanned
+            if (!final_ && mink != ~0u) {
+                int gap = 0x7fff;                                                    // distance to the nearest unscanned cell, over the open sides
+                if (x0 > 0) gap = min(gap, cx - (x0 << sh) + 1);
+                if (x1 < Gm1) gap = min(gap, ((x1 + 1) << sh) - cx);
+                if (y0 > 0) gap = min(gap, cy - (y0 << sh) + 1);
+                if (y1 < Gm1) gap = min(gap, ((y1 + 1) << sh) - cy);
+                const unsigned g2 = (unsigned)(gap * gap);                           // gap < 2^15: exact
+                const unsigned bfl = (unsigned)NNU((unsigned)__uint_as_float(mink)); // floor of the best squared distance (< 2^31)
+                final_ = bfl + 1u <= g2 - (g2 >> 18) - 1u && g2 > 1u;
+            }
+            if (final_) {
+                unsigned long long tie = __ballot(myk == mink);
+                if (tie & (tie - 1)) {                                               // several lanes hold this distance: the smallest index wins
+                    unsigned ci2 = myk == mink ? myi : 0x7fffffffu;
+                    for (int o = 32; o > 0; o >>= 1) { const unsigned t_ = (unsigned)__shfl_xor((int)ci2, o, 64); ci2 = t_ < ci2 ? t_ : ci2; }
+                    tie = __ballot(myk == mink && myi == ci2);
+                }
+                const int win_lane = __ffsll((long long)tie) - 1;
+                wi = (unsigned)__builtin_amdgcn_readlane((int)myi, win_lane);
+                w0 = (unsigned)__builtin_amdgcn_readlane((int)my0, win_lane);
+                w1 = (unsigned)__builtin_amdgcn_readlane((int)my1, win_lane);
+                break;
+            }
+        }
+        const int bi = (int)wi;
+        const int sx = (int)(w0 & 0x7fffu), sy = (int)((w0 >> 16) & 0x7fffu), ex = (int)(w1 & 0xffffu), ey = (int)(w1 >> 16);
+        const float ds = nn_d2(sx, sy, cx, cy), de = nn_d2(ex, ey, cx, cy);
+        const bool cl = (w0 & 0x80000000u) != 0;
+        const bool flip = cl ? false : !(ds <= de);
+        const int fl = NNU(flip ? 1 : 0);
+        if (lane == 0) reinterpret_cast<unsigned short*>(&P[bi])[0] = (unsigned short)((w0 & 0xffffu) | 0x8000u);
+        ringv = lane == (step & 63) ? (unsigned)((bi << 1) | fl) : ringv;
+        if ((step & 63) == 63) { order[step - 63 + lane] = (int32_t)(ringv >> 1); flips[step - 63 + lane] = (uint8_t)(ringv & 1u); }
+        if (cl || fl) { cx = sx; cy = sy; } else { cx = ex; cy = ey; }
+    }
+    { const int done = n & ~63; if (done + lane < n) { order[done + lane] = (int32_t)(ringv >> 1); flips[done + lane] = (uint8_t)(ringv & 1u); } }
+#undef NNU
+}
+
 // Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
 static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int64_t n = src.n;
@@ -589,16 +740,18 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     // grid side: as fine as LDS allows (cells are powers of two, so twice the side is four times fewer candidates per window),
     // but not many more cells than polylines
     int G = 8; while (G < 128 && (size_t)(G + 8) * (G + 8) <= 4 * (size_t)n && (size_t)n * 12 + (size_t)((G + 8) * (G + 8) + 1) * 4 + 64 <= 158 * 1024) G += 8;
-    const size_t lds_grid = (size_t)n * 12 + (size_t)(G * G + 1) * 4 + 64;
+    const size_t lds_grid = (size_t)n * 12 + (size_t)(G * G + 1) * 4 + 64;        // (+4 for k_greedy_nn_fast: inside the 64 spare bytes of the 158 KB check)
     static std::once_flag attr_once;                // several layer threads may arrive here together
     std::call_once(attr_once, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_grid), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     });
     if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {      // hs[1] == 0: every coordinate in [-2^14, 2^14)
         ProfScope ps(c, "k_greedy_nn");
         unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
-        hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips, dbg);
+        if (dbg || getenv("ORIP_NN_OLDGRID")) hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips, dbg);
+        else hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips);
         if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
     } else if (n <= 16000 && !(hs[1] & 1)) {
         ProfScope ps(c, "k_greedy_nn");
