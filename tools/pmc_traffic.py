@@ -3,8 +3,19 @@
 rocprofv3 reports both counters in units of 1024 B.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B read requests at
 64 B, i.e. wide coalesced reads show HALF their bytes; WRITE_SIZE is exact for wide stores; byte-granular / scattered accesses
 are uncalibrated.  The JSON keeps the raw sums and the per-launch averages so the correction stays visible."""
-import csv, json, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_digest():
+    """the kernel sources the counters were collected on (bench.py refuses the file when this no longer matches)"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "omnirevolve-image-processor_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 def load(path, name):
     acc = defaultdict(lambda: [0.0, 0])
@@ -23,8 +34,8 @@ for k in sorted(set(f) | set(w)):
     if not n: continue
     out[k] = {"launches": n, "fetch_kb_total": round(fs, 1), "write_kb_total": round(ws, 1),
               "fetch_bytes_per_launch_raw": int(fs * 1024 / max(fn, 1)), "write_bytes_per_launch": int(ws * 1024 / max(wn, 1))}
-json.dump({"unit_note": "raw counter x 1024 B; gfx950: FETCH_SIZE shows half the bytes of wide coalesced reads (MI355X_MICROARCH.md), other widths uncalibrated",
+json.dump({"csrc_digest": csrc_digest(), "unit_note": "raw counter x 1024 B; gfx950: FETCH_SIZE shows half the bytes of wide coalesced reads (MI355X_MICROARCH.md), other widths uncalibrated",
            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (two steps + the profiled one per pass)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k in ("k_trace", "k_write_walks", "k_lab_assign", "k_morph_pass", "k_thin_sub", "k_ccl_merge", "k_blur_sobel_nms"):
+for k in ("k_trace", "k_write_walks", "k_lab_assign", "k_nms_bits3", "k_morph_bits", "k_thin_bits04", "k_bits_to_skel_state", "k_greedy_nn_fast"):
     if k in out: print(k, out[k])
