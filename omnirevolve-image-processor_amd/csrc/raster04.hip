@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_thin_sub(const u8* __restrict__ src, u8
 }
 
 // ------------------------------------------------------------------------------------------------
-// state byte: bit0 fg, bit1 visited, bit2 endpoint (deg==1), bit3 junction (deg>=3)
+// state byte (walker.h): ST_FG, ST_VIS, ST_END (deg == 1), ST_JUN (deg >= 3)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_skel_state(const u8* __restrict__ skel, u8* __restrict__ st, int H, int W) {
     const size_t plane = (size_t)H * W;
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void k_compact_count(const u8* __restrict__ st
     __shared__ unsigned wsum[4];
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     unsigned cnt = 0;
-    if (i + 3 < n) { uint32_t w = *reinterpret_cast<const uint32_t*>(st + i); cnt = ((w & 1) != 0) + (((w >> 8) & 1) != 0) + (((w >> 16) & 1) != 0) + (((w >> 24) & 1) != 0); }
-    else for (int j = 0; j < 4; j++) if (i + j < n && (st[i + j] & 1)) cnt++;
+    if (i + 3 < n) { uint32_t w = *reinterpret_cast<const uint32_t*>(st + i); cnt = __popc(w & 0x80808080u); }        // ST_FG of four state bytes
+    else for (int j = 0; j < 4; j++) if (i + j < n && (st[i + j] & ST_FG)) cnt++;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
     __syncthreads();
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_compact_write(const u8* __restrict__ st
     const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const int64_t pplane = (int64_t)Wb * Hb * 4;
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     unsigned f[4]; unsigned cnt = 0;
-    for (int j = 0; j < 4; j++) { f[j] = (i + j < n) ? (st[i + j] & 1u) : 0u; cnt += f[j]; }
+    for (int j = 0; j < 4; j++) { f[j] = (i + j < n && (st[i + j] & ST_FG)) ? 1u : 0u; cnt += f[j]; }
     // inclusive scan of cnt across the wave via shuffles, then across waves via LDS
     unsigned inc = cnt;
     const int lane = threadIdx.x & 63;
@@ -468,6 +468,7 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
         HIPC(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, LN(c).stream));
         HIPC(c, hipStreamSynchronize(LN(c).stream));
         if (!over) break;
+        if (over == 2) ORIP_FAIL(c, "internal error: the walker of layer %d stopped making progress", layer);
         hipLaunchKernelGGL(k_clear_visited_layer, dim3(cdiv(Ml, 256)), block, 0, LN(c).stream, R.A.st + plane * layer, R.A.lin + b0, (int64_t)Ml);   // retry with larger logs
         ORIP_TRY(trace_launch(c, R, layer, R.F[layer] * 4));
     }

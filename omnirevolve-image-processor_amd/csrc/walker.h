@@ -28,10 +28,12 @@ struct int2 { int x, y; };
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 #endif
 typedef uint8_t u8;
-#define ST_FG 1
-#define ST_VIS 2
-#define ST_END 4
-#define ST_JUN 8
+// state byte of a skeleton pixel (state plane in memory and, plus two flag bits, the walker's LDS window): the two bits every step tests are
+// the top ones, so that "foreground" is `byte < 0` and "foreground, not visited" is `byte < -64` on the sign-extended byte (walker.h: Wave::run)
+#define ST_FG 0x80
+#define ST_VIS 0x40
+#define ST_JUN 2
+#define ST_END 1
 
 struct WalkInfo {            // one per potential walk: slot 2b+(q-b) for the endpoint walk starting at list index q, 2b+fg+(q-b) for a phase-2 walk
     unsigned len_kept;       // total points if the path is kept (>= 5 points, 04:224), else 0
@@ -88,16 +90,14 @@ struct Hot { unsigned steps, limit, nb, nbatch, allow; };   // allow = NEIGH8 di
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WT 64
 #define WTP (WT + 4)
-// window bytes (LDS), a re-coding of the state bytes that makes the two tests of a step one signed compare each:
-//   bit7 foreground, bit6 visited            ->  "foreground" = byte < 0, "foreground and not visited" = byte < -64
-//   bit5 ring cell of the window, bit4 start pixel of the walk (flags; the cursor may not probe from / walk through such a cell)
-//   bit1 junction, bit0 endpoint
-#define WB_FG 0x80
-#define WB_VIS 0x40
+// window bytes (LDS) = state bytes (bit7 foreground, bit6 visited, bit1 junction, bit0 endpoint) plus two flags:
+//   bit5 ring cell of the window, bit4 start pixel of the walk (the cursor may not probe from / walk through such a cell)
+#define WB_FG ST_FG
+#define WB_VIS ST_VIS
 #define WB_RING 0x20
 #define WB_HOME 0x10
-#define WB_JUN 2
-#define WB_END 1
+#define WB_JUN ST_JUN
+#define WB_END ST_END
 // One wavefront walks one component.  The walk is a strictly serial chain executed by a wave that has its SIMD to itself.  Measured on
 // MI355X for such a wave (tools/walkbench): every instruction ~4.5 cycles, a not-taken branch +10, a taken one 20, a scalar instruction
 // that consumes an SGPR written by a vector instruction (ballot, v_readlane) +16..20, an LDS read 44.  r01's compiled loop spent ~830
@@ -192,39 +192,55 @@ struct Wave {
         fence();                                                      // earlier marks have reached memory
         const int lead_x = lastk < 8 ? ((int)((0x9224u >> (2 * lastk)) & 3u) - 1) * ORIP_WALK_LEAD : 0;
         const int lead_y = lastk < 8 ? ((int)((0xA940u >> (2 * lastk)) & 3u) - 1) * ORIP_WALK_LEAD : 0;
-        tx0 = ((cx - WT / 2 + lead_x) >> 2) << 2; ty0 = cy - WT / 2 + lead_y;          // 4-byte aligned columns; the window leads in the direction of the last step
+        // 16-byte aligned columns; the window leads in the direction of the last step.  Rounding down moves the cursor up to 15 columns to the
+        // right inside the window, so the nominal column is 24, not 32: the cursor lands in columns [8, 55], never on the ring (a cursor that
+        // still stood on the ring after a reload would re-place the window for ever)
+        tx0 = ((cx - (WT / 2 - 8) + lead_x) >> 4) << 4; ty0 = cy - WT / 2 + lead_y;
         const int y = ty0 + lane;
         u8* row = tile + lane * WTP;
         const uint32_t ring_row = (lane == 0 || lane == WT - 1) ? 0x20202020u : 0u;     // first and last row: every cell
-        auto recode = [](uint32_t w) -> uint32_t { return ((w & 0x01010101u) << 7) | ((w & 0x02020202u) << 5) | ((w >> 2) & 0x03030303u); };
         if (y < 0 || y >= H) { for (int j = 0; j < WT; j += 4) *reinterpret_cast<uint32_t*>(row + j) = 0x20202020u; }   // outside the image: not foreground; the flag is harmless
-        else if ((W & 3) == 0 && tx0 >= 0 && tx0 + WT <= W) {
+        else if ((W & 15) == 0 && tx0 >= 0 && tx0 + WT <= W && (tx0 & 15) == 0 && ((uintptr_t)st & 15) == 0) {
+            // 64 bytes per row as four 16-byte loads that bypass the CU's L1 (the plane is updated with atomics, see or_visited)
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u* src = reinterpret_cast<const v4u*>(st + (size_t)y * W + tx0);
+            v4u q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = __builtin_nontemporal_load(src + j);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w4[4] = {q[j].x | ring_row, q[j].y | ring_row, q[j].z | ring_row, q[j].w | ring_row};
+                if (j == 0) w4[0] |= 0x20u;
+                if (j == 3) w4[3] |= 0x20000000u;
+#pragma unroll
+                for (int t = 0; t < 4; t++) *reinterpret_cast<uint32_t*>(row + 16 * j + 4 * t) = w4[t];
+            }
+        } else if ((W & 3) == 0 && tx0 >= 0 && tx0 + WT <= W && ((uintptr_t)st & 3) == 0) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (size_t)y * W + tx0);
             uint32_t w[WT / 4];
 #pragma unroll
             for (int j = 0; j < WT / 4; j++) w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int j = 0; j < WT / 4; j++) {
-                uint32_t x = recode(w[j]) | ring_row;
+                uint32_t x = w[j] | ring_row;
                 if (j == 0) x |= 0x20u;
                 if (j == WT / 4 - 1) x |= 0x20000000u;
                 *reinterpret_cast<uint32_t*>(row + 4 * j) = x;
             }
         } else {
             for (int j = 0; j < WT; j++) {
-                int x = tx0 + j; u8 g = (x >= 0 && x < W) ? ld_state((unsigned)((size_t)y * W + x)) : (u8)0;
-                u8 bte = (u8)recode(g);
+                int x = tx0 + j; u8 bte = (x >= 0 && x < W) ? ld_state((unsigned)((size_t)y * W + x)) : (u8)0;
                 if (ring_row || j == 0 || j == WT - 1) bte |= WB_RING;
                 row[j] = bte;
             }
         }
         have = true; nload++;
-        fence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // (LDS is in order for one wave: the flag below lands after the rows)
         if (home != ~0u && steps > 0 && lane == 0) {                  // the start pixel of the walk inside the new window
             const int hx = (int)(home % (unsigned)W) - tx0, hy = (int)(home / (unsigned)W) - ty0;
             if ((unsigned)hx < (unsigned)WT && (unsigned)hy < (unsigned)WT) tile[hy * WTP + hx] |= WB_HOME;
         }
-        fence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         WPROF_ADD(t_tile, t_0);
     }
     __device__ void set_cursor(unsigned lin) { pl = lin; reload = true; lastk = 8; }
@@ -273,7 +289,7 @@ struct Wave {
         rec = lane == (int)(steps & 63u) ? r : rec;
         if (fresh) tile[va] = (u8)(v | (int)((sel >> k) & WB_VIS));   // every lane writes its byte back, lane k with the visited bit: no exec juggling
         reload = (vk & WB_RING) != 0;
-        return (u8)(ST_FG | ((vk & WB_VIS) || fresh ? ST_VIS : 0) | ((vk & WB_END) ? ST_END : 0) | ((vk & WB_JUN) ? ST_JUN : 0));
+        return (u8)((vk & (ST_FG | ST_VIS | ST_END | ST_JUN)) | (fresh ? ST_VIS : 0));
     }
     // after EV_DEAD: 2 = the cursor stands on the start pixel of the walk, 1 = it stood on the window ring (window re-placed), 0 = neither
     __device__ int resume_flagged(unsigned steps) {
@@ -304,13 +320,18 @@ struct Wave {
         }
         return (key != 0 && best != ~0u) ? best : 0u;
     }
-    // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS)
-    __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
-        for (unsigned q = q0; q < e; q += 64) {
-            unsigned qq = q + lane; bool ok = false;
-            if (qq < e) { u8 x = ld_state(lin[qq]); ok = ((x & need) == need) && !(x & ST_VIS); }
+    // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS).  The scans of a component move forward through its
+    // pixel list in small steps, so the list entries are kept 64 at a time in a VGPR (lin_blk = entries [lin_q0, lin_q0 + 64)): a scan then costs
+    // one memory round trip (the state bytes) instead of two dependent ones.
+    unsigned lin_blk = 0, lin_q0 = ~0u;
+    __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) {
+        for (unsigned q = q0; q < e; ) {
+            if (q < lin_q0 || q >= lin_q0 + 64u) { lin_q0 = q; lin_blk = (q + (unsigned)lane < e) ? lin[q + lane] : 0u; }
+            const unsigned qq = lin_q0 + (unsigned)lane; bool ok = false;
+            if (qq >= q && qq < e) { u8 x = ld_state(lin_blk); ok = ((x & need) == need) && !(x & ST_VIS); }
             unsigned long long m = __ballot(ok);
-            if (m) return q + (unsigned)(__ffsll((long long)m) - 1);
+            if (m) return lin_q0 + (unsigned)(__ffsll((long long)m) - 1);
+            q = lin_q0 + 64u;
         }
         return e;
     }
@@ -550,7 +571,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     const unsigned log_base = F * b + 64u * c, log_cap = F * fg + 64u;
     const unsigned step_base = F * b + 256u * c, step_cap = F * fg + 256u;
     unsigned logcur = 0, stepcur = 0;
-    bool over = false;
+    bool over = false, stalled = false;
     unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
     unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0, t_f3 = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
@@ -595,7 +616,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     // ends the walk there and the steps taken after it are dropped; otherwise all of them become provisional entries of this run.
     const unsigned g2 = fg * 4u;                                  // guard of a leftover walk (04:199)
     const unsigned nbatch0 = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
-    for (unsigned q = tscan(b, ST_FG); q < e && !over; q = tscan(q + 1, ST_FG)) {
+    for (unsigned q = tscan(b, ST_FG); q < e && !over && !stalled; q = tscan(q + 1, ST_FG)) {
         unsigned s = A.lin[q];
         wv.set_cursor(s);
         const unsigned sbeg = step_base + stepcur;
@@ -666,6 +687,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         };
         auto flush = [&]() -> int { const unsigned long long t_0 = WPROF_NOW(); n_flush++; const int r = flush_(); WPROF_ADD(t_flush, t_0); return r; };
         int ended = 0;
+        unsigned stall = 0, stall_steps = ~0u;
         while (true) {
             if (h.steps >= room) { over = true; break; }
             unsigned lim = (h.steps & ~63u) + 64u;                    // the records of 64 steps fit the lanes: codes and marks leave at every multiple of 64
@@ -676,7 +698,11 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             n_ev++;
             if (ev == EV_DEAD) {
                 const int f = wv.resume_flagged(h.steps);             // GPU: a flagged window cell stops the loop the same way
-                if (f == 1) continue;                                 // window re-placed
+                if (f == 1) {                                         // window re-placed (or a stale flag cleared): go on
+                    if (h.steps == stall_steps && ++stall > 8u) { stalled = true; break; }     // ... unless nothing moves: a bug, never a hang
+                    if (h.steps != stall_steps) { stall_steps = h.steps; stall = 0; }
+                    continue;
+                }
                 if (f == 0) break;                                    // no neighbour at all (04:187-188)
                 ev = EV_HOME;
             }
@@ -705,6 +731,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
     }
     if (over && wv.leader()) *A.overflow = 1;
+    if (stalled && wv.leader()) *A.overflow = 2;                   // internal error: the host reports it instead of retrying
     if (A.dbg && wv.leader()) {
         unsigned long long* d = A.dbg + 16ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
         d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3;     // cycle counts: ORIP_WALK_PROF builds only
