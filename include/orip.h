@@ -67,6 +67,12 @@ int orip_prof_reset(orip_ctx* ctx);
 int orip_prof_get(orip_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
 int orip_prof_enable(orip_ctx* ctx, int on);
 
+/* ---- stage 01: 01_resize.py ---- */
+/* cv2.resize(img, (newW, newH), interpolation=cv2.INTER_AREA) for shrinking (01:19; the size rule int(w * max_dimension / max(h, w)) of 01:15-18
+ * stays on the host).  src u8 [H,W,cn] (host), cn 1..4; dst u8 [newH,newW,cn] (host) may be NULL.  as_image != 0 (cn == 3): the result is left as
+ * the context's image as orip_set_image would leave it, so the resident chain needs no resized.png. */
+int orip_resize_area(orip_ctx* ctx, const uint8_t* src, int H, int W, int cn, int newH, int newW, uint8_t* dst, int as_image);
+
 /* ---- stage 02: 02_color_extract.py ---- */
 /* upload the pixels of resized.png (BGR u8 [H,W,3]) -- replaces cv2.imread at 02:70-71 */
 int orip_set_image(orip_ctx* ctx, const uint8_t* bgr, int H, int W);

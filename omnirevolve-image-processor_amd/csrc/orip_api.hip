@@ -57,6 +57,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     orip_comm_destroy(c);
     c->comm_sizes.release();
     c->stream_segs.release(); c->stream_off.release(); c->stream_codes.release();
+    c->resize_src.release(); c->resize_dst.release();
     delete c;
 }
 

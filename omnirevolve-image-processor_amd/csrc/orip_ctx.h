@@ -128,6 +128,7 @@ struct orip_ctx {
     DBuf comm_sizes;
     // 13_build_stream: moves and their direction codes (stream.hip), resident between orip_stream_codes and the fetch
     DBuf stream_segs, stream_off, stream_codes; int64_t stream_n = 0, stream_total = 0;
+    DBuf resize_src, resize_dst;                       // raster01.hip staging
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;

@@ -54,6 +54,17 @@ class Device:
         self._ck(self.L.orip_prof_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    # ---- stage 01
+    def resize_area(self, img: np.ndarray, new_w: int, new_h: int, as_image: bool = False, fetch: bool = True):
+        """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_AREA) for shrinking (01:19); as_image leaves the result as the stage-02 image"""
+        img = np.ascontiguousarray(img, np.uint8)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((new_h, new_w) if img.ndim == 2 else (new_h, new_w, cn), np.uint8) if fetch else None
+        self._ck(self.L.orip_resize_area(self.h, _p(img), img.shape[0], img.shape[1], cn, new_h, new_w, _p(out) if fetch else None, int(as_image)))
+        if as_image:
+            self.H, self.W = new_h, new_w
+        return out
+
     # ---- stage 02
     def set_image(self, bgr: np.ndarray):
         bgr = np.ascontiguousarray(bgr, np.uint8)

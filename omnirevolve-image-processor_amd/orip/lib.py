@@ -39,6 +39,7 @@ _P = C.POINTER
 SIGNATURES = {
     "orip_create": (_i32, [_i32, _P(_vp)]), "orip_destroy": (None, [_vp]), "orip_last_error": (_cp, [_vp]), "orip_sync": (_i32, [_vp]),
     "orip_prof_reset": (_i32, [_vp]), "orip_prof_get": (_i32, [_vp, _cp, _P(_f64), _P(_i64)]), "orip_prof_enable": (_i32, [_vp, _i32]),
+    "orip_resize_area": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32]),
     "orip_set_image": (_i32, [_vp, _vp, _i32, _i32]), "orip_lab_of": (_i32, [_vp, _vp, _i64, _vp]),
     "orip_kmeans_fit": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _P(_f64)]),
     "orip_extract_layers": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),

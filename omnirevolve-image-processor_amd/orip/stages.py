@@ -116,6 +116,23 @@ def r_insert12(cfg: Config) -> float:  # 12:197
 
 
 # ---------------------------------------------------------------- stage functions (host arrays in / out)
+def resized_size(h: int, w: int, max_dimension: int):
+    """01:12-18 -- None when the longest side already fits, else (new_w, new_h) with Python's float scale and int() truncation"""
+    m = max(h, w)
+    if m <= max_dimension:
+        return None
+    scale = max_dimension / m
+    return int(w * scale), int(h * scale)
+
+
+def resize_if_needed(img: np.ndarray, cfg: Config, dev: Device | None = None, as_image: bool = False) -> np.ndarray:
+    """01 resize_if_needed (:7-23): the image itself when it fits, else its INTER_AREA shrink; as_image also leaves it resident for stage 02"""
+    size = resized_size(img.shape[0], img.shape[1], int(cfg.max_dimension))
+    if size is None:
+        return img
+    return (dev or device()).resize_area(img, size[0], size[1], as_image=as_image)
+
+
 def extract_colors(bgr: np.ndarray, cfg: Config, centers: np.ndarray | None = None, dev: Device | None = None):
     """02 main(), k-means mode.  Returns (masks {name: u8[H,W]}, info) with info = centres (dark->light), counts, labels."""
     d = dev or device()

@@ -37,7 +37,7 @@ def main():
     masks = {}
     for name in cfg.color_names:
         p = os.path.join(cfg.output_dir, name, "mask.png")
-        if not os.path.exists(p):
+        if not _io.exists(p):
             raise FileNotFoundError(f"Mask not found: {p}")
         m = _io.read_gray(p)
         if m is None:

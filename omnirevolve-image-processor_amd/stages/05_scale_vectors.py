@@ -18,7 +18,7 @@ def main():
         cdir = os.path.join(cfg.output_dir, name)
         os.makedirs(cdir, exist_ok=True)
         src = os.path.join(cdir, "contours.pkl")
-        if not os.path.exists(src):
+        if not _io.exists(src):
             print(f"[scale] {name}: missing {src}, skipping")
             continue
         contours = _io.load_pickle(src)

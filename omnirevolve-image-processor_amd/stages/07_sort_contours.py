@@ -12,9 +12,9 @@ def main():
         cdir = os.path.join(cfg.output_dir, name)
         os.makedirs(cdir, exist_ok=True)
         src = os.path.join(cdir, "contours_scaled.pkl")
-        if not os.path.exists(src):
+        if not _io.exists(src):
             src = os.path.join(cdir, "contours.pkl")
-        if not os.path.exists(src):
+        if not _io.exists(src):
             print(f"[sort] skip (missing): {src}")
             continue
         contours = _io.load_pickle(src)

@@ -11,7 +11,7 @@ def main():
     for name in cfg.color_names:
         layer_dir = os.path.join(cfg.output_dir, name)
         src = os.path.join(layer_dir, "contours_sorted.pkl")
-        if not os.path.exists(src):
+        if not _io.exists(src):
             raise RuntimeError(f"[intra] missing input: {src}. Run step 06 first.")
         polys = _io.load_pickle(src)
         if not isinstance(polys, list):

@@ -16,11 +16,11 @@ def main():
         os.makedirs(layer_dir, exist_ok=True)
         pL, pT = os.path.join(layer_dir, "lines_intra.pkl"), os.path.join(layer_dir, "taps_intra.pkl")
         lines, taps = [], []
-        if os.path.exists(pL):
+        if _io.exists(pL):
             lines = _io.load_pickle(pL)
         else:
             print(f"[cross] WARNING: missing {pL}")
-        if os.path.exists(pT):
+        if _io.exists(pT):
             for it in _io.load_pickle(pT):
                 a = np.asarray(it).reshape(-1)
                 if a.size >= 2:

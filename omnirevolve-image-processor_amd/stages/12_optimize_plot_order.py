@@ -18,7 +18,7 @@ def main():
         layer_dir = os.path.join(out, name)
         os.makedirs(layer_dir, exist_ok=True)
         pL, pT = os.path.join(layer_dir, "lines_cross.pkl"), os.path.join(layer_dir, "taps_cross.pkl")
-        if not os.path.exists(pL) or not os.path.exists(pT):
+        if not _io.exists(pL) or not _io.exists(pT):
             raise SystemExit(f"Missing cross artifacts in {layer_dir}")
         lines = _io.load_pickle(pL)
         taps = []

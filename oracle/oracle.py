@@ -46,7 +46,7 @@ def lib():
             "orc_lab_tables": (None, [vp, vp, vp]), "orc_bgr2lab": (None, [vp, i64, vp]),
             "orc_kmeans": (f64, [vp, i32, i32, i32, i32, f64, vp]), "orc_assign": (None, [vp, i64, vp, i32, vp]),
             "orc_morph_open_close": (None, [vp, i32, i32, i32, i32, i32, i32]), "orc_make_se": (None, [i32, i32, vp]),
-            "orc_gaussian": (i32, [vp, vp, i32, i32, i32]), "orc_canny": (None, [vp, vp, i32, i32, i32, i32]),
+            "orc_gaussian": (i32, [vp, vp, i32, i32, i32]), "orc_resize_area": (i32, [vp, i32, i32, i32, vp, i32, i32]), "orc_canny": (None, [vp, vp, i32, i32, i32, i32]),
             "orc_thin_rot": (i32, [vp, vp, i32, i32]), "orc_zs_std": (i32, [vp, vp, i32, i32, i32]),
             "orc_ccl8": (i32, [vp, vp, i32, i32]), "orc_trace": (None, [vp, i32, i32, vp]),
             "orc_stamp_capsule": (None, [vp, i32, i32, i32, i32, i32, i32, i32]),
@@ -194,6 +194,25 @@ def make_se(shape: int, k: int) -> np.ndarray:
     se = np.zeros((k, k), np.uint8)
     lib().orc_make_se(shape, k, _p(se))
     return se
+
+
+def resize_area(img, new_w: int, new_h: int) -> np.ndarray:
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_AREA) for shrinking (01:19); parity unpinned (OpenCV absent)"""
+    a = np.ascontiguousarray(img, np.uint8)
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    out = np.empty((new_h, new_w) if a.ndim == 2 else (new_h, new_w, cn), np.uint8)
+    if lib().orc_resize_area(_p(a), a.shape[0], a.shape[1], cn, _p(out), new_h, new_w) != 0:
+        raise ValueError(f"resize_area: {a.shape[1]}x{a.shape[0]} -> {new_w}x{new_h} is not a shrink")
+    return out
+
+
+def resize_if_needed(img, max_dimension: int = 2000) -> np.ndarray:  # 01:7-23
+    h, w = img.shape[:2]
+    m = max(h, w)
+    if m <= max_dimension:
+        return img
+    s = max_dimension / m
+    return resize_area(img, int(w * s), int(h * s))
 
 
 def gaussian(img, k: int) -> np.ndarray:

@@ -39,6 +39,7 @@ void orc_morph_open_close(u8* img, int H, int W, int shape, int k, int open_iter
     morph_open_close(img, H, W, shape, k, open_iters, close_iters);
 }
 void orc_make_se(int shape, int k, u8* se) { std::vector<u8> v; make_se(shape, k, v); memcpy(se, v.data(), v.size()); }
+int orc_resize_area(const u8* src, int sh, int sw, int cn, u8* dst, int dh, int dw) { return resize_area(src, sh, sw, cn, dst, dh, dw); }
 int orc_gaussian(const u8* src, u8* dst, int H, int W, int k) { return gaussian_blur(src, dst, H, W, k); }
 void orc_canny(const u8* src, u8* dst, int H, int W, int low, int high) { canny(src, dst, H, W, low, high); }
 int orc_thin_rot(const u8* e, u8* s, int H, int W) { return thinning_rot(e, s, H, W); }

@@ -82,6 +82,7 @@ void morph(const u8* src, u8* dst, int H, int W, const u8* se, int kh, int kw, b
 void make_se(int shape /*0 rect, 2 ellipse*/, int k, std::vector<u8>& se);
 void morph_open_close(u8* img, int H, int W, int shape, int k, int open_iters, int close_iters);
 int gaussian_blur(const u8* src, u8* dst, int H, int W, int k);
+int resize_area(const u8* src, int sh, int sw, int cn, u8* dst, int dh, int dw);
 void canny(const u8* src, u8* dst, int H, int W, int low, int high);
 int thinning_rot(const u8* edges, u8* skel, int H, int W);          // 04:35-99
 int zhang_suen_std(const u8* src, u8* dst, int H, int W, int max_iter);  // 08:342-372

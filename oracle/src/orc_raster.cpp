@@ -544,4 +544,71 @@ void trace_centerlines(const u8* skel, int H, int W, PolyList& out) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 01_resize.py:19 -- cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_AREA), shrinking only.
+// PARITY UNPINNED (cv2 is absent): restated from OpenCV 4.x imgproc/src/resize.cpp as published --
+//   * both ratios integers (|scale - round| < DBL_EPSILON): resizeAreaFast_: 2 x 2 -> (a + b + c + d + 2) >> 2; otherwise the integer cell
+//     sum times float(1 / area), rounded half-to-even (saturate_cast<uchar>(float) is cvRound);
+//   * otherwise resizeArea_: per axis a table of (source index, destination index, float alpha) from computeResizeAreaTab (partial cell on the left
+//     when more than 1e-3 of it is inside, whole cells with alpha 1 / cellWidth, partial cell on the right), rows reduced in float in table order
+//     (buf += S * alpha), then destination rows in float (sum = beta * buf for the first source row of a destination row, sum += beta * buf after).
+// The x86 wheels run this code path without fused multiply-add (baseline SSE build), which is what -ffp-contract=off gives here.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct AreaTab { int si, di; float alpha; };
+void area_tab(int ssize, int dsize, double scale, std::vector<AreaTab>& tab) {
+    tab.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) tab.push_back({sx1 - 1, dx, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; sx++) tab.push_back({sx, dx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) tab.push_back({sx2, dx, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)});
+    }
+}
+inline u8 round_u8(float v) { const long r = lrintf(v); return (u8)(r < 0 ? 0 : r > 255 ? 255 : r); }   // default rounding mode: half to even
+}  // namespace
+
+int resize_area(const u8* src, int sh, int sw, int cn, u8* dst, int dh, int dw) {
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || dh > sh || dw > sw || cn < 1 || cn > 4) return -1;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    if (std::abs(scale_x - isx) < DBL_EPSILON && std::abs(scale_y - isy) < DBL_EPSILON) {
+        const int area = isx * isy; const float inv = 1.f / area;
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int sum = 0;
+                    for (int sy = 0; sy < isy; sy++)
+                        for (int sx = 0; sx < isx; sx++) sum += src[((size_t)(dy * isy + sy) * sw + dx * isx + sx) * cn + c];
+                    dst[((size_t)dy * dw + dx) * cn + c] = (isx == 2 && isy == 2) ? (u8)((sum + 2) >> 2) : round_u8(sum * inv);
+                }
+        return 0;
+    }
+    std::vector<AreaTab> xt, yt;
+    area_tab(sw, dw, scale_x, xt); area_tab(sh, dh, scale_y, yt);
+    std::vector<float> buf((size_t)dw * cn), sum((size_t)dw * cn, 0.f);
+    int prev_dy = yt.empty() ? 0 : yt[0].di;
+    for (size_t j = 0; j < yt.size(); j++) {
+        const float beta = yt[j].alpha; const int dy = yt[j].di;
+        const u8* S = src + (size_t)yt[j].si * sw * cn;
+        std::fill(buf.begin(), buf.end(), 0.f);
+        for (const AreaTab& e : xt)
+            for (int c = 0; c < cn; c++) buf[(size_t)e.di * cn + c] = buf[(size_t)e.di * cn + c] + S[(size_t)e.si * cn + c] * e.alpha;
+        if (dy != prev_dy) {
+            u8* D = dst + (size_t)prev_dy * dw * cn;
+            for (size_t i = 0; i < sum.size(); i++) { D[i] = round_u8(sum[i]); sum[i] = beta * buf[i]; }
+            prev_dy = dy;
+        } else {
+            for (size_t i = 0; i < sum.size(); i++) sum[i] += beta * buf[i];
+        }
+    }
+    u8* D = dst + (size_t)prev_dy * dw * cn;
+    for (size_t i = 0; i < sum.size(); i++) D[i] = round_u8(sum[i]);
+    return 0;
+}
 }  // namespace orc

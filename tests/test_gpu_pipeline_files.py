@@ -74,3 +74,33 @@ def test_missing_input_aborts_with_nonzero_exit(tmp_path):
     env = dict(os.environ, CONFIG_PATH=str(out / "config.json"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "omnirevolve-image-processor_amd", "stages", "08_dedup_layer_basic.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "missing input" in (r.stdout + r.stderr)
+
+
+def test_raw_npy_side_channel(tmp_path):
+    """ORIP_RAW_NPY=1: every raster also as .png.npy, every polyline list also as .pkl.npz; a later stage reads the raw file even
+    when the PNG / pickle it mirrors is gone, and the chain's results are the ones of the codec path."""
+    from PIL import Image
+    from orip.synth import synth_image, layer_names
+    K = 4
+    img = synth_image(120, 150, K, seed=21, sigma=5.0)
+    out = tmp_path / "out"; out.mkdir()
+    Image.fromarray(img[:, :, ::-1]).save(out / "resized.png")
+    (out / "config.json").write_text(json.dumps({"output_dir": str(out), "color_names": layer_names(K), "pixels_per_mm": 6}))
+    env = dict(os.environ, ORIP_RAW_NPY="1")
+    pl = os.path.join(ROOT, "omnirevolve-image-processor_amd", "stages", "pipeline.py")
+    r = subprocess.run([sys.executable, pl, "in.png", "--output", str(out), "--start-step", "2", "--end-step", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = O.run_pipeline(img, dict(O.DEFAULTS, color_names=layer_names(K), pixels_per_mm=6))
+    for n in layer_names(K):
+        assert np.array_equal(np.load(out / n / "mask.png.npy"), want["masks"][n]) and np.array_equal(np.load(out / n / "edges.png.npy"), want["edges"][n])
+        z = np.load(out / n / "contours.pkl.npz")
+        assert same_polys([z["pts"][z["off"][i]:z["off"][i + 1]] for i in range(len(z["off"]) - 1)], want["contours"][n])
+        os.remove(out / n / "contours.pkl")                 # from here on only the raw lists exist for stage 05
+    r = subprocess.run([sys.executable, pl, "in.png", "--output", str(out), "--start-step", "5", "--end-step", "12"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for n in layer_names(K):
+        with open(out / n / "ops.pkl", "rb") as fh:
+            ops = pickle.load(fh)
+        assert [o["type"] for o in ops] == [o["type"] for o in want["ops"][n]]
+        for a, b in zip(ops, want["ops"][n]):
+            assert np.array_equal(a["points"], b["points"]) if a["type"] == "line" else (a["x"], a["y"]) == (b["x"], b["y"])
