@@ -81,6 +81,16 @@ int orip_lab_of(orip_ctx* ctx, const int64_t* idx, int64_t n, uint8_t* lab_out);
 /* _kmeans_lab fit part (02:39-49): Lab of the sampled pixels + cv2.kmeans(PP centres, attempts, (EPS|ITER)) */
 int orip_kmeans_fit(orip_ctx* ctx, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter,
                     double eps, float* centers_out /* [K,3] in cv2.kmeans order */, double* compactness_out);
+/* ---- process_colors.py (standalone label-map tool) ---- */
+/* kmeans_palette (:31-46): cv2.kmeans (PP centres) over the R, G, B bytes of the sampled pixels of the image set with orip_set_image; same
+ * arguments as orip_kmeans_fit, centres in R, G, B order.  The subsample (:35-39, numpy RandomState) stays on the host. */
+int orip_kmeans_fit_rgb(orip_ctx* ctx, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter,
+                        double eps, float* centers_out /* [K,3] */, double* compactness_out);
+/* assign_labels (:69-77): index of the nearest palette colour per pixel, with the reference's int16 arithmetic (squares of differences above
+ * 181 wrap) and first-minimum ties.  palette_rgb u8 [K,3].  Leaves the labels resident (orip_get_labels); labels_out (host u8 [H,W]) and
+ * counts_out ([K] pixels per label) may be NULL. */
+int orip_assign_palette(orip_ctx* ctx, const uint8_t* palette_rgb, int K, uint8_t* labels_out, int64_t* counts_out);
+
 /* assignment (02:53-55) + dark->light relabel (02:120-127) + per-cluster mask + 3x3 RECT open/close (02:144-154).
  * Leaves labels u8 [H,W] (dark->light index) and K masks resident; layer l of the context = cluster l. */
 int orip_extract_layers(orip_ctx* ctx, const float* centers /* [K,3] */, int K, int open_iters, int close_iters,

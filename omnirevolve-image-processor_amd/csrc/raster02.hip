@@ -117,6 +117,40 @@ __global__ __launch_bounds__(256) void k_lab_gather(const u8* __restrict__ bgr, 
     }
 }
 
+// process_colors.py kmeans_palette (:31-46) clusters RGB bytes, not Lab: the sampled pixels in R, G, B order
+__global__ __launch_bounds__(256) void k_rgb_gather(const u8* __restrict__ bgr, const int64_t* __restrict__ idx, int64_t n, u8* __restrict__ rgb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = idx ? idx[i] : i;
+        rgb[3 * i] = bgr[3 * p + 2]; rgb[3 * i + 1] = bgr[3 * p + 1]; rgb[3 * i + 2] = bgr[3 * p];
+    }
+}
+// process_colors.py assign_labels (:69-77): nearest palette colour in RGB with the reference's int16 arithmetic -- the squares of differences
+// above 181 wrap to negative values before they are summed (in int64), and np.argmin takes the first minimum.  Four pixels per thread (12 bytes in,
+// 4 bytes out), the palette in LDS.
+__global__ __launch_bounds__(256) void k_assign_palette(const u8* __restrict__ bgr, int64_t npx, const u8* __restrict__ pal_rgb, int K, u8* __restrict__ labels) {
+    __shared__ int pr[ORIP_MAX_LAYERS], pg[ORIP_MAX_LAYERS], pb[ORIP_MAX_LAYERS];
+    if (threadIdx.x < K) { pr[threadIdx.x] = pal_rgb[3 * threadIdx.x]; pg[threadIdx.x] = pal_rgb[3 * threadIdx.x + 1]; pb[threadIdx.x] = pal_rgb[3 * threadIdx.x + 2]; }
+    __syncthreads();
+    auto sq16 = [](int d) { return (int)(int16_t)(uint16_t)(d * d); };
+    auto nearest = [&](int b, int g, int r) {
+        int best = 0x7fffffff, bi = 0;
+        for (int k = 0; k < K; k++) { const int d = sq16(r - pr[k]) + sq16(g - pg[k]) + sq16(b - pb[k]); if (d < best) { best = d; bi = k; } }
+        return bi;
+    };
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;                  // group of four pixels
+    if (4 * q + 3 < npx) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(bgr) + 3 * q;    // hipMalloc'd, 12-byte groups: dword aligned
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const unsigned l0 = nearest(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);
+        const unsigned l1 = nearest(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+        const unsigned l2 = nearest((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+        const unsigned l3 = nearest((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
+        reinterpret_cast<uint32_t*>(labels)[q] = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
+    } else {
+        for (int64_t i = 4 * q; i < npx; i++) labels[i] = (u8)nearest(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2]);
+    }
+}
+
 __global__ void k_count_labels(const u8* __restrict__ labels, int64_t n, unsigned long long* counts) {
     __shared__ unsigned int h[ORIP_MAX_LAYERS];
     if (threadIdx.x < ORIP_MAX_LAYERS) h[threadIdx.x] = 0;
@@ -826,8 +860,8 @@ extern "C" int orip_lab_of(orip_ctx* c, const int64_t* idx, int64_t n, uint8_t* 
     return 0;
 }
 
-extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
-                               float* centers_out, double* compactness_out) {
+static int kmeans_fit_impl(orip_ctx* c, bool rgb, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
+                           float* centers_out, double* compactness_out) {
     orip_enter(c);
     c->mask_bits = nullptr;
     if (!c->image.p) ORIP_FAIL(c, "no image set");
@@ -836,7 +870,10 @@ extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n
     if (N < K || N > 0x7fffffff) ORIP_FAIL(c, "bad sample count %lld", (long long)N);
     HIPC(c, c->tmpB.ensure((size_t)N * 3 + 16));
     if (sample_idx) { HIPC(c, c->tmpC.ensure((size_t)N * 8)); HIPC(c, hipMemcpyAsync(c->tmpC.p, sample_idx, (size_t)N * 8, hipMemcpyHostToDevice, LN(c).stream)); }
-    {
+    if (rgb) {
+        hipLaunchKernelGGL(k_rgb_gather, dim3(std::min<int64_t>(2048, cdiv(N, 256))), dim3(256), 0, LN(c).stream, c->image.as<u8>(),
+                           sample_idx ? c->tmpC.as<int64_t>() : nullptr, N, c->tmpB.as<u8>());
+    } else {
         ProfScope ps(c, "k_lab_gather");
         hipLaunchKernelGGL(k_lab_gather, dim3(std::min<int64_t>(2048, cdiv(N, 256))), dim3(256), 0, LN(c).stream, c->image.as<u8>(),
                            sample_idx ? c->tmpC.as<int64_t>() : nullptr, N, c->tmpB.as<u8>(), c->lab_tabs.as<LabTabs>());
@@ -873,6 +910,46 @@ extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n
     if (st != 0) ORIP_FAIL(c, "kmeans kernel did not complete (status %d)", st);
     memcpy(centers_out, hc.cen, sizeof(float) * K * 3);
     if (compactness_out) *compactness_out = comp;
+    return 0;
+}
+
+extern "C" int orip_kmeans_fit(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
+                               float* centers_out, double* compactness_out) {
+    return kmeans_fit_impl(c, false, sample_idx, n_idx, K, attempts, max_iter, eps, centers_out, compactness_out);
+}
+extern "C" int orip_kmeans_fit_rgb(orip_ctx* c, const int64_t* sample_idx, int64_t n_idx, int K, int attempts, int max_iter, double eps,
+                                   float* centers_out, double* compactness_out) {
+    return kmeans_fit_impl(c, true, sample_idx, n_idx, K, attempts, max_iter, eps, centers_out, compactness_out);
+}
+
+// process_colors.py assign_labels: labels u8 [H,W] of the image against an RGB palette, resident (orip_get_labels) and optionally on the host
+extern "C" int orip_assign_palette(orip_ctx* c, const uint8_t* palette_rgb, int K, uint8_t* labels_out, int64_t* counts_out) {
+    orip_enter(c);
+    c->mask_bits = nullptr;
+    if (!c->image.p) ORIP_FAIL(c, "no image set");
+    if (!palette_rgb || K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range 1..%d", K, ORIP_MAX_LAYERS);
+    const int64_t npx = (int64_t)c->H * c->W;
+    hipStream_t s = LN(c).stream;
+    HIPC(c, c->labels.ensure((size_t)npx + 16));
+    HIPC(c, LN(c).flags.ensure(1024));
+    u8* d_pal = (u8*)LN(c).flags.p + 768;
+    HIPC(c, hipMemcpyAsync(d_pal, palette_rgb, (size_t)K * 3, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(c, "k_assign_palette");
+        hipLaunchKernelGGL(k_assign_palette, dim3((unsigned)cdiv(cdiv(npx, 4), 256)), dim3(256), 0, s, c->image.as<u8>(), npx, d_pal, K, c->labels.as<u8>());
+    }
+    HIPC(c, hipGetLastError());
+    if (counts_out) {
+        unsigned long long* d_counts = (unsigned long long*)((char*)LN(c).flags.p + 512);
+        HIPC(c, hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * ORIP_MAX_LAYERS, s));
+        hipLaunchKernelGGL(k_count_labels, dim3(512), dim3(256), 0, s, c->labels.as<u8>(), npx, d_counts);
+        unsigned long long h[ORIP_MAX_LAYERS];
+        HIPC(c, hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, s));
+        HIPC(c, hipStreamSynchronize(s));
+        for (int k = 0; k < K; k++) counts_out[k] = (int64_t)h[k];
+    }
+    if (labels_out) HIPC(c, hipMemcpyAsync(labels_out, c->labels.p, (size_t)npx, hipMemcpyDeviceToHost, s));
+    HIPC(c, hipStreamSynchronize(s));
     return 0;
 }
 

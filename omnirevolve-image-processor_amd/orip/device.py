@@ -96,6 +96,23 @@ class Device:
             self._ck(self.L.orip_kmeans_fit(self.h, _p(idx), len(idx), K, attempts, max_iter, eps, _p(centers), C.byref(comp)))
         return centers, comp.value
 
+    # ---- process_colors.py
+    def kmeans_fit_rgb(self, sample_idx: np.ndarray | None, K: int, attempts=3, max_iter=30, eps=1.0) -> Tuple[np.ndarray, float]:
+        """kmeans_palette's cv2.kmeans (process_colors.py:41-45) over the R, G, B bytes of the sampled pixels; float centres in R, G, B order"""
+        centers = np.zeros((K, 3), np.float32)
+        comp = C.c_double(0)
+        idx = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int64)
+        self._ck(self.L.orip_kmeans_fit_rgb(self.h, _p(idx) if idx is not None else None, 0 if idx is None else len(idx), K, attempts, max_iter, eps, _p(centers), C.byref(comp)))
+        return centers, comp.value
+
+    def assign_palette(self, palette_rgb: np.ndarray, fetch: bool = True):
+        """assign_labels (process_colors.py:69-77): (labels u8 [H,W] or None, pixels per label)"""
+        pal = np.ascontiguousarray(palette_rgb, np.uint8).reshape(-1, 3)
+        labels = np.empty((self.H, self.W), np.uint8) if fetch else None
+        counts = np.zeros(len(pal), np.int64)
+        self._ck(self.L.orip_assign_palette(self.h, _p(pal), len(pal), _p(labels) if fetch else None, _p(counts)))
+        return labels, counts
+
     def extract_layers(self, centers: np.ndarray, open_iters=1, close_iters=1, want_counts=True):
         c = np.ascontiguousarray(centers, np.float32)
         K = len(c)

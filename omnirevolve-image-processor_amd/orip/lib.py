@@ -42,6 +42,7 @@ SIGNATURES = {
     "orip_resize_area": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32]),
     "orip_set_image": (_i32, [_vp, _vp, _i32, _i32]), "orip_lab_of": (_i32, [_vp, _vp, _i64, _vp]),
     "orip_kmeans_fit": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _P(_f64)]),
+    "orip_kmeans_fit_rgb": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _P(_f64)]), "orip_assign_palette": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "orip_extract_layers": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "orip_get_labels": (_i32, [_vp, _vp]), "orip_get_mask": (_i32, [_vp, _i32, _vp]), "orip_set_masks": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "orip_keep_layers": (_i32, [_vp, _vp, _i32]),

@@ -215,6 +215,32 @@ def resize_if_needed(img, max_dimension: int = 2000) -> np.ndarray:  # 01:7-23
     return resize_area(img, int(w * s), int(h * s))
 
 
+def assign_labels_rgb(img_rgb, palette_rgb) -> np.ndarray:
+    """process_colors.py assign_labels (:69-77): int16 differences, int16 products (they wrap above |181|), int64 sums, first minimum"""
+    px = np.ascontiguousarray(img_rgb, np.uint8).reshape(-1, 3).astype(np.int32)
+    pal = np.ascontiguousarray(palette_rgb, np.uint8).reshape(-1, 3).astype(np.int32)
+    best = None; lab = np.zeros(len(px), np.uint8)
+    for k in range(len(pal)):
+        d = px - pal[k]
+        sq = ((d * d + 32768) & 0xffff) - 32768              # what an int16 multiplication leaves
+        dist = sq.sum(axis=1, dtype=np.int64)
+        if best is None:
+            best = dist
+        else:
+            upd = dist < best
+            lab[upd] = k; best = np.where(upd, dist, best)
+    return lab.reshape(np.asarray(img_rgb).shape[:2])
+
+
+def kmeans_palette_rgb(img_rgb, k: int, samples: int = 200000, seed: int = 1) -> np.ndarray:
+    """process_colors.py kmeans_palette (:31-46); cv2.kmeans through this oracle's restatement: parity unpinned"""
+    flat = np.ascontiguousarray(img_rgb, np.uint8).reshape(-1, 3)
+    if len(flat) > samples:
+        flat = flat[np.random.RandomState(seed).choice(len(flat), size=samples, replace=False)]
+    centers, _ = kmeans(flat.astype(np.float32), k, attempts=3, max_iter=30, eps=1.0)
+    return centers.astype(np.uint8)
+
+
 def gaussian(img, k: int) -> np.ndarray:
     a = np.ascontiguousarray(img, np.uint8); out = np.empty_like(a)
     if lib().orc_gaussian(_p(a), _p(out), a.shape[0], a.shape[1], k) != 0:
