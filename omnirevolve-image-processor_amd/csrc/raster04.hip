@@ -318,14 +318,19 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);
         if (c->edge_bits != (const void*)bA) hipLaunchKernelGGL(k_bytes_to_bits04, gw, block, 0, LN(c).stream, c->edges.as<u8>(), bA, H, W, Ww);   // stage 03 may have left them
         c->edge_bits = nullptr;
-        for (int it = 0; it < 120; it++) {
-            HIPC(c, hipMemsetAsync(d_changed, 0, 4, LN(c).stream));
-            { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_changed); }
-            { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bB, bA, H, Ww, 1, d_changed); }
-            int h_changed = 0;
-            HIPC(c, hipMemcpyAsync(&h_changed, d_changed, 4, hipMemcpyDeviceToHost, LN(c).stream));
+        // two iterations per round trip to the host, each with its own flag (an iteration after an unchanged one changes nothing either)
+        int* d_ch2 = LN(c).flags.as<int>() + 212;
+        for (int it = 0; it < 120; it += 2) {
+            HIPC(c, hipMemsetAsync(d_ch2, 0, 8, LN(c).stream));
+            for (int b = 0; b < 2; b++) {
+                ProfScope ps(c, "k_thin_bits");
+                hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_ch2 + b);
+                hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bB, bA, H, Ww, 1, d_ch2 + b);
+            }
+            int h_changed[2] = {0, 0};
+            HIPC(c, hipMemcpyAsync(h_changed, d_ch2, 8, hipMemcpyDeviceToHost, LN(c).stream));
             HIPC(c, hipStreamSynchronize(LN(c).stream));
-            if (!h_changed) break;
+            if (!(h_changed[0] && h_changed[1])) break;
         }
         { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_bits_to_skel_state, gw, block, 0, LN(c).stream, bA, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W, Ww); }
     } else {

@@ -1,5 +1,5 @@
 """The dispatches of ONE queue (default: the one holding the longest k_trace) in the last run of a rocprofv3 --kernel-trace CSV, in order,
-with the idle gap before each and a per-kernel total (development aid).  usage: python tools/chain_of_queue.py <dir-or-csv> [MIN_MS] [QUEUE]"""
+with the idle gap before each and a per-kernel total (development aid).  usage: python tools/chain_of_queue.py <dir-or-csv> [MIN_MS] [QUEUE|-] [FROM_MS]"""
 import csv, glob, os, re, sys
 from collections import defaultdict
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
@@ -15,11 +15,12 @@ sel = [r for r in rows if r[0] >= t0]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"void rocprim::.*::detail::", "rp::", n)
     return n[:56]
-if len(sys.argv) > 3:
+t_from = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+if len(sys.argv) > 3 and sys.argv[3] != "-":
     Q = sys.argv[3]
 else:
     Q = max((e - s, q) for s, e, n, q in sel if "k_trace" in n)[1]
-ch = [r for r in sel if r[3] == Q]
+ch = [r for r in sel if r[3] == Q and (r[0] - t0) / 1e6 >= t_from]
 print(f"queue {Q}: {len(ch)} dispatches, busy {sum(e - s for s, e, n, q in ch)/1e6:.1f} ms, span {(ch[0][0]-t0)/1e6:.1f} .. {(ch[-1][1]-t0)/1e6:.1f} ms")
 tot = defaultdict(lambda: [0, 0.0]); prev = ch[0][0]; small = 0.0; nsmall = 0; gap_small = 0.0
 for s, e, n, q in ch:
