@@ -470,7 +470,14 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         }
         auto t3 = tdbg ? now() : t0;
         // ---- 5) paint lines (exact disc dilation of all vertices)
-        if (Lout.total > 0) {
+        // Few vertices (the usual case after stage 08: tens of thousands on a 100-Mpixel canvas): one disc per vertex, written directly.  The
+        // separable passes below cost three sweeps of the whole canvas whatever the number of vertices and only win when the discs would cover
+        // it several times over.  Same predicate either way: (x - vx)^2 + (y - vy)^2 <= r^2 for some vertex.
+        const long long disc_px = (long long)(2 * rad_lines + 1) * (2 * rad_lines + 1);
+        if (Lout.total > 0 && (long long)Lout.total * disc_px <= (long long)W * H && Lout.total <= 0x7fffffff && !getenv("ORIP_PAINT_SEPARABLE")) {
+            ProfScope ps(c, "k_stamp_discs");
+            hipLaunchKernelGGL(k_stamp_discs, dim3((unsigned)std::min<int64_t>(Lout.total, 65535)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), (int)Lout.total, rad_lines, forb, H, W);
+        } else if (Lout.total > 0) {
             HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, LN(c).stream));
             HIPC(c, hipMemsetAsync(occ, 0, (size_t)occ_w * occ_h, LN(c).stream));
             hipLaunchKernelGGL(k_seed_mark, dim3(cdiv(Lout.total, 256)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, seeds, Hp, Wp, occ, occ_w);

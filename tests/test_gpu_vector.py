@@ -93,8 +93,14 @@ def test_stage10_golden(dev, G):
         assert same_polys(out[n][0], unflat(G, f"lines_cross_{n}")), n
 
 
-def test_stage10_random_vs_oracle(dev):
+@pytest.mark.parametrize("paint", ["discs", "separable"])
+def test_stage10_random_vs_oracle(dev, monkeypatch, paint):
+    """both ways of painting a layer's lines into the forbidden raster (one disc per vertex / separable distance passes)"""
     from orip import stages as S
+    if paint == "separable":
+        monkeypatch.setenv("ORIP_PAINT_SEPARABLE", "1")
+    else:
+        monkeypatch.delenv("ORIP_PAINT_SEPARABLE", raising=False)
     rng = np.random.default_rng(5)
     cfgd = dict(O.DEFAULTS, pixels_per_mm=8, color_names=["layer_dark", "layer_mid", "x_extra", "layer_light"])   # canvas 1680x2376
     cfg = _cfgobj(cfgd)

@@ -1,4 +1,4 @@
-"""Idle gaps of the critical queue in the last run of a rocprofv3 --kernel-trace CSV: every gap of at least MIN_MS with the dispatches on either side
+"""Idle gaps of the critical queue in one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) of a rocprofv3 --kernel-trace CSV: every gap of at least MIN_MS with the dispatches on either side
 (development aid: a gap is a host round trip, a wait for another queue, or host work).  usage: python tools/chain_gaps.py <dir-or-csv> [MIN_MS]"""
 import csv, glob, os, re, sys
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.08
@@ -9,8 +9,9 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
-t0 = max(s for s, e, n, q in rows if "k_kmeans_fit" in n)
-sel = [r for r in rows if r[0] >= t0]
+starts = [s for s, e, n, q in rows if "k_kmeans_fit" in n]          # one per run of the path; run 1 = the first timed step of bench.py --warmup 1
+RUN = int(os.environ.get("ORIP_TRACE_RUN", "1")); t0 = starts[RUN]; t_end = starts[RUN + 1] if RUN + 1 < len(starts) else 1 << 62
+sel = [r for r in rows if t0 <= r[0] < t_end]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"void rocprim::.*::detail::", "rp::", n)
     return n[:40]

@@ -1,4 +1,4 @@
-"""The dispatches of ONE queue (default: the one holding the longest k_trace) in the last run of a rocprofv3 --kernel-trace CSV, in order,
+"""The dispatches of ONE queue (default: the one holding the longest k_trace) in one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) of a rocprofv3 --kernel-trace CSV, in order,
 with the idle gap before each and a per-kernel total (development aid).  usage: python tools/chain_of_queue.py <dir-or-csv> [MIN_MS] [QUEUE|-] [FROM_MS]"""
 import csv, glob, os, re, sys
 from collections import defaultdict
@@ -10,8 +10,9 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
-t0 = max(s for s, e, n, q in rows if "k_kmeans_fit" in n)
-sel = [r for r in rows if r[0] >= t0]
+starts = [s for s, e, n, q in rows if "k_kmeans_fit" in n]          # one per run of the path; run 1 = the first timed step of bench.py --warmup 1
+RUN = int(os.environ.get("ORIP_TRACE_RUN", "1")); t0 = starts[RUN]; t_end = starts[RUN + 1] if RUN + 1 < len(starts) else 1 << 62
+sel = [r for r in rows if t0 <= r[0] < t_end]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\(.*", "", n); n = re.sub(r"void rocprim::.*::detail::", "rp::", n)
     return n[:56]

@@ -1,4 +1,4 @@
-"""Timeline of the last run inside a rocprofv3 --kernel-trace CSV: dispatches after the last k_kmeans_fit launch that last
+"""Timeline of one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) inside a rocprofv3 --kernel-trace CSV: dispatches after the last k_kmeans_fit launch that last
 longer than MIN_MS, by start time (development aid).  usage: python tools/trace_timeline.py <dir-or-csv> [MIN_MS]"""
 import csv, glob, os, re, sys
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
@@ -9,8 +9,9 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
 rows.sort()
-t0 = max(s for s, e, n, q, g in rows if "k_kmeans_fit" in n)
-sel = [r for r in rows if r[0] >= t0]
+starts = [s for s, e, n, q, g in rows if "k_kmeans_fit" in n]          # one per run of the path; run 1 = the first timed step of bench.py --warmup 1
+RUN = int(os.environ.get("ORIP_TRACE_RUN", "1")); t0 = starts[RUN]; t_end = starts[RUN + 1] if RUN + 1 < len(starts) else 1 << 62
+sel = [r for r in rows if t0 <= r[0] < t_end]
 end = max(e for s, e, n, q, g in sel)
 print(f"run: {(end - t0)/1e6:.1f} ms, {len(sel)} dispatches, busy kernel time {sum(e-s for s,e,n,q,g in sel)/1e6:.1f} ms")
 def short(n):
