@@ -287,6 +287,39 @@ __global__ __launch_bounds__(256) void k_col_cover(const u8* __restrict__ hd, u8
         if (cov) forb[o] = 255;
     }
 }
+// Discs of radius r around the vertices of a chain, written as set differences: vertex i only writes the part of its disc that the disc of vertex
+// i - 1 does not hold (for the unit steps of the stage's lines a sickle of a few pixels per row; the full disc when the two do not overlap).  By
+// induction the union of what is written is the union of the discs, whatever the order the threads run in.  One thread per (vertex, row).
+__global__ __launch_bounds__(256) void k_stamp_chain(const int2* __restrict__ pts, int64_t n, int r, u8* __restrict__ forb, int H, int W) {
+    __shared__ int hw[2 * CC_RMAX + 4];                        // half width of the disc at row offset d: floor(sqrt(r^2 - d^2))
+    const int side = 2 * r + 1;
+    for (int d = threadIdx.x; d < side; d += 256) {
+        const int dy = d - r; const int q = r * r - dy * dy;
+        int w = (int)sqrtf((float)q);
+        while (w * w > q) w--;
+        while ((w + 1) * (w + 1) <= q) w++;
+        hw[d] = w;
+    }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * side) return;
+    const int64_t i = t / side; const int d = (int)(t - i * side);
+    const int2 v = pts[i];
+    const int y = v.y + d - r;
+    if (y < 0 || y >= H) return;
+    int lo = v.x - hw[d], hi = v.x + hw[d];
+    int plo = 1, phi = 0;                                      // span of the previous vertex's disc on this row (empty)
+    if (i > 0) {
+        const int2 p = pts[i - 1];
+        const int dp = y - p.y;
+        if (dp >= -r && dp <= r) { plo = p.x - hw[dp + r]; phi = p.x + hw[dp + r]; }
+    }
+    lo = max(lo, 0); hi = min(hi, W - 1);
+    u8* row = forb + (size_t)y * W;
+    if (plo > phi) { for (int x = lo; x <= hi; x++) row[x] = 255; return; }
+    for (int x = lo; x <= min(hi, plo - 1); x++) row[x] = 255;
+    for (int x = max(lo, phi + 1); x <= hi; x++) row[x] = 255;
+}
 __global__ __launch_bounds__(256) void k_stamp_discs(const int2* __restrict__ taps, int n, int r, u8* __restrict__ forb, int H, int W) {
     for (int t = blockIdx.x; t < n; t += gridDim.x) {
         int cx = taps[t].x, cy = taps[t].y; int side = 2 * r + 1;
@@ -470,13 +503,13 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         }
         auto t3 = tdbg ? now() : t0;
         // ---- 5) paint lines (exact disc dilation of all vertices)
-        // Few vertices (the usual case after stage 08: tens of thousands on a 100-Mpixel canvas): one disc per vertex, written directly.  The
-        // separable passes below cost three sweeps of the whole canvas whatever the number of vertices and only win when the discs would cover
-        // it several times over.  Same predicate either way: (x - vx)^2 + (y - vy)^2 <= r^2 for some vertex.
-        const long long disc_px = (long long)(2 * rad_lines + 1) * (2 * rad_lines + 1);
-        if (Lout.total > 0 && (long long)Lout.total * disc_px <= (long long)W * H && Lout.total <= 0x7fffffff && !getenv("ORIP_PAINT_SEPARABLE")) {
-            ProfScope ps(c, "k_stamp_discs");
-            hipLaunchKernelGGL(k_stamp_discs, dim3((unsigned)std::min<int64_t>(Lout.total, 65535)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), (int)Lout.total, rad_lines, forb, H, W);
+        // The usual case after stage 08 (tens of thousands of vertices on a 100-Mpixel canvas): discs written directly, each vertex only what its
+        // predecessor's disc does not hold (k_stamp_chain).  The separable passes below cost three sweeps of the whole canvas whatever the number
+        // of vertices and only win for vertex counts in the order of the canvas.  Same predicate either way: (x - vx)^2 + (y - vy)^2 <= r^2.
+        const long long chain_threads = (long long)Lout.total * (2 * rad_lines + 1);
+        if (Lout.total > 0 && rad_lines <= CC_RMAX && chain_threads <= 4ll * W * H && chain_threads < (1ll << 39) && !getenv("ORIP_PAINT_SEPARABLE")) {
+            ProfScope ps(c, "k_stamp_chain");
+            hipLaunchKernelGGL(k_stamp_chain, dim3((unsigned)((chain_threads + 255) / 256)), dim3(256), 0, LN(c).stream, reinterpret_cast<const int2*>(Lout.pts.p), Lout.total, rad_lines, forb, H, W);
         } else if (Lout.total > 0) {
             HIPC(c, hipMemsetAsync(seeds, 0, (size_t)Wp * Hp, LN(c).stream));
             HIPC(c, hipMemsetAsync(occ, 0, (size_t)occ_w * occ_h, LN(c).stream));
