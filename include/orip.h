@@ -109,6 +109,10 @@ int orip_set_edges(orip_ctx* ctx, const uint8_t* edges, int K, int H, int W);
 
 /* ---- stage 04: 04_find_contours.py vectorize_layer (04:214-230), all layers in one call ---- */
 int orip_find_contours(orip_ctx* ctx);
+/* Optional hint for the resident chain (no counterpart in the reference): after orip_set_image, announce that K layers will be traced so that the
+ * K memo planes of stage 04 are cleared while the k-means fit runs instead of underneath stages 02 / 03.  orip_contours_prepare works without it. */
+int orip_contours_reserve(orip_ctx* ctx, int K);
+
 /* The same work split for per-layer pipelines: prepare = the part batched over the layers (thinning 04:35-99, components, walk
  * schedule); contours_layer = the walks of one layer (04:101-211), callable for different layers from different host threads. */
 int orip_contours_prepare(orip_ctx* ctx);

@@ -129,6 +129,7 @@ struct orip_ctx {
     // 13_build_stream: moves and their direction codes (stream.hip), resident between orip_stream_codes and the fetch
     DBuf stream_segs, stream_off, stream_codes; int64_t stream_n = 0, stream_total = 0;
     DBuf resize_src, resize_dst;                       // raster01.hip staging
+    int memo_pre_K = 0, memo_pre_H = 0, memo_pre_W = 0; // orip_contours_reserve cleared this many memo planes of an H x W image
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;

@@ -284,6 +284,24 @@ __global__ __launch_bounds__(256) void k_kept_slots_base(const unsigned* __restr
 
 // Everything of stage 04 that is batched over the layers: thinning, components, state bytes, the raster-ordered pixel list
 // sorted by component, the per-layer schedule.  Runs on lane 0 and ends synchronised.
+// Hint for the resident chain: the image is set and K layers will be traced.  Clears the K memo planes on the layer lanes NOW -- at the start of a
+// step the card is idle but for the k-means fit, whereas 4 GB of fills issued from orip_contours_prepare run into stages 02 / 03 -- and
+// orip_contours_prepare then skips its own clearing.  Nothing else touches lane 0's vtmp[6] in between.
+extern "C" int orip_contours_reserve(orip_ctx* c, int K) {
+    orip_enter(c);
+    if (!c->image.p || c->H <= 0 || c->W <= 0) ORIP_FAIL(c, "no image set");
+    if (K < 1 || K > ORIP_MAX_LAYERS) ORIP_FAIL(c, "K=%d out of range 1..%d", K, ORIP_MAX_LAYERS);
+    const size_t plane = (size_t)c->H * c->W;
+    c->memo_pre_K = 0;
+    HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
+    for (int l = 0; l < K; l++) {
+        ORIP_LANE(c, l + 1);
+        HIPC(c, hipMemsetAsync(c->ln[0].vtmp[6].as<unsigned>() + plane * 8 * l, 0, plane * 8 * 4, LN(c).stream));
+    }
+    c->memo_pre_K = K; c->memo_pre_H = c->H; c->memo_pre_W = c->W;
+    return 0;
+}
+
 extern "C" int orip_contours_prepare(orip_ctx* c) {
     orip_enter(c);
     if (!c->edges.p || c->K < 1) ORIP_FAIL(c, "no edges resident (run orip_detect_edges or orip_set_edges)");
@@ -294,12 +312,16 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     R.ready = false; R.K = K;
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) { R.launched[l] = false; R.F[l] = 0; R.memo_clear[l] = false; }
     const size_t plane = (size_t)H * W; const int64_t n = (int64_t)plane * K;
-    // the memo planes (one word per pixel and incoming direction, 0.5 GB per layer at 4096^2) are cleared on the layer lanes now,
-    // underneath the raster work below, instead of in front of every layer's trace
+    // the memo planes (one word per pixel and incoming direction, 0.5 GB per layer at 4096^2) are cleared on the layer lanes, not in front of
+    // every layer's trace: by orip_contours_reserve at the start of the step when the caller gave that hint, else now, underneath the raster work below
+    const bool pre = c->memo_pre_K >= K && c->memo_pre_H == H && c->memo_pre_W == W;
+    c->memo_pre_K = 0;
     HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
     for (int l = 0; l < K; l++) {
-        ORIP_LANE(c, l + 1);
-        HIPC(c, hipMemsetAsync(c->ln[0].vtmp[6].as<unsigned>() + plane * 8 * l, 0, plane * 8 * 4, LN(c).stream));
+        if (!pre) {
+            ORIP_LANE(c, l + 1);
+            HIPC(c, hipMemsetAsync(c->ln[0].vtmp[6].as<unsigned>() + plane * 8 * l, 0, plane * 8 * 4, LN(c).stream));
+        }
         R.memo_clear[l] = true;
     }
     // ---- thinning_zhangsuen (04:35-99): <=120 iterations of two sub-iterations, until nothing is deleted
@@ -323,9 +345,8 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         for (int it = 0; it < 120; it += 2) {
             HIPC(c, hipMemsetAsync(d_ch2, 0, 8, LN(c).stream));
             for (int b = 0; b < 2; b++) {
-                ProfScope ps(c, "k_thin_bits");
-                hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_ch2 + b);
-                hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bB, bA, H, Ww, 1, d_ch2 + b);
+                { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bA, bB, H, Ww, 0, d_ch2 + b); }
+                { ProfScope ps(c, "k_thin_bits"); hipLaunchKernelGGL(k_thin_bits04, gw, block, 0, LN(c).stream, bB, bA, H, Ww, 1, d_ch2 + b); }
             }
             int h_changed[2] = {0, 0};
             HIPC(c, hipMemcpyAsync(h_changed, d_ch2, 8, hipMemcpyDeviceToHost, LN(c).stream));

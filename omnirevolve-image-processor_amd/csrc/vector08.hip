@@ -1248,9 +1248,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             for (int it = 0; it < 48; it += 4) {
                 HIPC(c, hipMemsetAsync(d_ch4, 0, 16, LN(c).stream));
                 for (int b = 0; b < 4; b++) {
-                    ProfScope ps(c, "k_zs_sub");
-                    hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_ch4 + b);
-                    hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_ch4 + b);
+                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_ch4 + b); }
+                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_ch4 + b); }
                 }
                 int ch[4] = {0, 0, 0, 0}; ORIP_TRY(vread(c, ch, d_ch4, 4));
                 if (!(ch[0] && ch[1] && ch[2] && ch[3])) break;

@@ -162,6 +162,10 @@ class Device:
     def find_contours(self):
         self._ck(self.L.orip_find_contours(self.h))
 
+    def contours_reserve(self, K: int):
+        """hint: K layers of the image just set will be traced (clears stage 04's memo planes while the card is idle)"""
+        self._ck(self.L.orip_contours_reserve(self.h, int(K)))
+
     def contours_prepare(self):
         self._ck(self.L.orip_contours_prepare(self.h))
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "orip_keep_layers": (_i32, [_vp, _vp, _i32]),
     "orip_detect_edges": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "orip_get_edges": (_i32, [_vp, _i32, _vp]), "orip_set_edges": (_i32, [_vp, _vp, _i32, _i32, _i32]),
-    "orip_find_contours": (_i32, [_vp]), "orip_contours_prepare": (_i32, [_vp]), "orip_contours_layer": (_i32, [_vp, _i32]),
+    "orip_find_contours": (_i32, [_vp]), "orip_contours_prepare": (_i32, [_vp]), "orip_contours_reserve": (_i32, [_vp, _i32]), "orip_contours_layer": (_i32, [_vp, _i32]),
     "orip_dedup_cross_begin": (_i32, [_vp, _P(Params10)]), "orip_dedup_cross_layer": (_i32, [_vp, _i32]), "orip_dedup_cross_layer_from": (_i32, [_vp, _i32, _i32]), "orip_dedup_cross_layer_deferred": (_i32, [_vp, _i32, _i32]), "orip_get_skeleton": (_i32, [_vp, _i32, _vp]),
     "orip_polys_size": (_i32, [_vp, _i32, _i32, _P(_i64), _P(_i64)]), "orip_get_polys": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "orip_set_polys": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp]),

@@ -171,6 +171,7 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
     names = list(cfg.color_names)
     K = max(2, len(names))
     lnames = S.cluster_names(cfg)[:K]
+    dev.contours_reserve(K if world == 1 else len(owned_layers(K, rank, world)))      # memo planes cleared under the k-means fit
     centers, _ = dev.kmeans_fit(S.subsample_indices(H * W), K)
     dev.extract_layers(centers, want_counts=False)
     order = sorted(range(K), key=lambda l: (S.darkness_rank10(lnames[l]), names.index(lnames[l])))

@@ -256,6 +256,8 @@ def run_path(bgr: np.ndarray, cfg: Config, dev: Device | None = None, centers: n
     lnames = cluster_names(cfg)[:K]
     H, W = bgr.shape[:2]
     d.set_image(bgr)
+    if upto >= 5:
+        d.contours_reserve(K)
     if centers is None:
         centers, _ = d.kmeans_fit(subsample_indices(H * W), K)
     d.extract_layers(np.asarray(centers, np.float32), want_counts=False)
