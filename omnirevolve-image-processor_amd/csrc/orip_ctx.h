@@ -156,6 +156,11 @@ struct ProfScope {
     }
 };
 
+// raise a kernel's dynamic-LDS limit; the result is kept so that every caller (not only the one thread that ran the std::call_once) sees a failure
+template <class F> static inline void orip_max_lds(F* kernel, int bytes, std::atomic<int>& err) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) err.store((int)e);
+}
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // stage entry points implemented across the .hip files

@@ -742,11 +742,13 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int G = 8; while (G < 128 && (size_t)(G + 8) * (G + 8) <= 4 * (size_t)n && (size_t)n * 12 + (size_t)((G + 8) * (G + 8) + 1) * 4 + 64 <= 158 * 1024) G += 8;
     const size_t lds_grid = (size_t)n * 12 + (size_t)(G * G + 1) * 4 + 64;        // (+4 for k_greedy_nn_fast: inside the 64 spare bytes of the 158 KB check)
     static std::once_flag attr_once;                // several layer threads may arrive here together
+    static std::atomic<int> attr_err{0};
     std::call_once(attr_once, [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_grid), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_nn_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        orip_max_lds(k_greedy_nn_lds, 150 * 1024, attr_err);
+        orip_max_lds(k_greedy_nn_grid, 158 * 1024, attr_err);
+        orip_max_lds(k_greedy_nn_fast, 158 * 1024, attr_err);
     });
+    if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(greedy kernels) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
     if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {      // hs[1] == 0: every coordinate in [-2^14, 2^14)
         ProfScope ps(c, "k_greedy_nn");
         unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;

@@ -284,7 +284,9 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
     const size_t lds = (size_t)nl * 17 + (size_t)nt * 9 + 64;
     if (lds <= 150 * 1024 && !getenv("ORIP_PLOT_1WG")) {
         static std::once_flag attr_once;            // several layer threads may arrive here together
-        std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_plot_order_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+        static std::atomic<int> attr_err{0};
+        std::call_once(attr_once, [&] { orip_max_lds(k_plot_order_wave, 150 * 1024, attr_err); });
+        if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(k_plot_order_wave) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
         ProfScope ps(c, "k_plot_order");
         hipLaunchKernelGGL(k_plot_order_wave, dim3(1), dim3(64), lds, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, c->ops[layer].as<int32_t>(), d_n);
     } else { ProfScope ps(c, "k_plot_order"); hipLaunchKernelGGL(k_plot_order, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)nl, T.xy.as<int32_t>(), (int)nt, R_insert, alive_l, alive_t, c->ops[layer].as<int32_t>(), d_n); }

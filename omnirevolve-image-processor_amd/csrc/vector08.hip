@@ -1345,7 +1345,9 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 CompArgs A; A.corder = corder; A.cs = cs; A.lin = lin; A.gid = gid; A.g = grp; A.cid = cid; A.nbr = nbr; A.Wp = Wp; A.min_len = P.post_minlen; A.step = stp;
                 A.eps = (float)P.post_eps; A.outpts = outpts; A.outcnt = outcnt;
                 static std::once_flag attr_once;            // several layer threads may arrive here together
-                std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_paths_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); });
+                static std::atomic<int> attr_err{0};
+                std::call_once(attr_once, [&] { orip_max_lds(k_comp_paths_lds, (int)lds1, attr_err); });
+                if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(k_comp_paths_lds) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
                 ProfScope ps(c, "k_comp_paths");
                 // the few large components are long serial chains: they start on the side stream while the many small ones run here
                 HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));

@@ -526,7 +526,9 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
             const size_t lds_t = (size_t)n_seq * 17 + 64;
             if (lds_t <= 150 * 1024 && !getenv("ORIP_TAPS_1WG")) {
                 static std::once_flag attr_once;            // several layer threads may arrive here together
-                std::call_once(attr_once, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k_taps_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+                static std::atomic<int> attr_err{0};
+                std::call_once(attr_once, [&] { orip_max_lds(k_taps_wave, 150 * 1024, attr_err); });
+                if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(k_taps_wave) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
                 ProfScope ps(c, "k_taps_sequential");
                 hipLaunchKernelGGL(k_taps_wave, dim3(1), dim3(64), lds_t, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n);
             } else { ProfScope ps(c, "k_taps_sequential"); hipLaunchKernelGGL(k_taps_sequential, dim3(1), dim3(1024), 0, LN(c).stream, seq, (int)n_seq, rad_taps, forb, H, W, acc, d_n); }
