@@ -134,6 +134,9 @@ int orip_scale_vectors(orip_ctx* ctx, int layer, float sx, float sy, float dx, f
 int orip_sort_contours(orip_ctx* ctx, int layer);
 /* ---- stage 08: process_layer (08:484-557): SORTED -> LINES_INTRA + TAPS_INTRA ---- */
 int orip_dedup_layer(orip_ctx* ctx, int layer, const orip_params08* prm);
+/* orip_contours_layer + orip_scale_vectors [+ orip_sort_contours [+ orip_dedup_layer]] of one layer in one call (upto = 5, 7 or 8; prm may be NULL
+ * below 8): the per-layer front of a resident chain without returning to the caller between the stages.  Same lane rules as the single calls. */
+int orip_layer_front(orip_ctx* ctx, int layer, float sx, float sy, float dx, float dy, int upto, const orip_params08* prm);
 /* ---- stage 10: main (10:212-278): LINES/TAPS_INTRA -> LINES/TAPS_CROSS, layers visited in `order` ---- */
 int orip_dedup_cross(orip_ctx* ctx, const int32_t* order, int n_layers, const orip_params10* prm);
 /* The same loop one layer at a time (10:230-262): begin clears the cumulative raster, then the layers must be passed in `order`. */

@@ -1380,3 +1380,17 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (tdbg) fprintf(stderr, "[time08] layer %d (in %lld polys %lld pts, kept %lld pts, cleaned %lld/%lld, lines2 %lld/%lld):%s\n", layer, (long long)S.n, (long long)S.total, (long long)kept0.p.total, (long long)cleaned.p.n, (long long)cleaned.p.total, (long long)lines2.p.n, (long long)lines2.p.total, tlog.c_str());
     return 0;
 }
+
+// The front of one layer's pipeline in ONE call: orip_contours_layer -> orip_scale_vectors -> [orip_sort_contours -> [orip_dedup_layer]] (upto = 5, 7
+// or 8) on the layer's lane.  Same results as the four calls; what goes away are the returns to the (Python) caller between the stages of a resident
+// chain -- three hand-overs per layer, each 0.2-0.5 ms of idle stream on the critical layer.
+extern "C" int orip_layer_front(orip_ctx* c, int layer, float sx, float sy, float dx, float dy, int upto, const orip_params08* prm) {
+    orip_enter(c);
+    if (upto >= 8 && !prm) ORIP_FAIL(c, "stage 08 needs its parameters");
+    ORIP_TRY(orip_contours_layer(c, layer));
+    ORIP_TRY(orip_scale_vectors(c, layer, sx, sy, dx, dy));
+    if (upto >= 7) ORIP_TRY(orip_sort_contours(c, layer));
+    if (upto >= 8) ORIP_TRY(orip_dedup_layer(c, layer, prm));
+    return 0;
+}
+

@@ -228,6 +228,10 @@ class Device:
     def dedup_layer(self, layer: int, prm: _l.Params08):
         self._ck(self.L.orip_dedup_layer(self.h, layer, C.byref(prm)))
 
+    def layer_front(self, layer: int, sx, sy, dx, dy, upto: int, prm: _l.Params08 | None):
+        """contours_layer -> scale_vectors [-> sort_contours [-> dedup_layer]] (upto 5 / 7 / 8) in one call on the layer's lane"""
+        self._ck(self.L.orip_layer_front(self.h, layer, np.float32(sx), np.float32(sy), np.float32(dx), np.float32(dy), int(upto), C.byref(prm) if prm is not None else None))
+
     def dedup_cross(self, order: Sequence[int], prm: _l.Params10):
         o = np.ascontiguousarray(np.asarray(list(order), np.int32))
         self._ck(self.L.orip_dedup_cross(self.h, _p(o), len(o), C.byref(prm)))

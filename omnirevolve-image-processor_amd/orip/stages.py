@@ -340,8 +340,5 @@ def layer_front(d: Device, cfg: Config, W: int, H: int, upto: int = 8):
     p8 = params08(cfg)
 
     def front(l):
-        d.contours_layer(l)
-        d.scale_vectors(l, sx, sy, dx, dy)
-        if upto >= 7: d.sort_contours(l)
-        if upto >= 8: d.dedup_layer(l, p8)
+        d.layer_front(l, sx, sy, dx, dy, 8 if upto >= 8 else (7 if upto >= 7 else 5), p8)
     return front
