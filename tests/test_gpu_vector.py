@@ -127,12 +127,14 @@ def test_stage12_golden(dev, G):
         assert same_polys(got, unflat(G, f"ops_{n}")), n
 
 
-@pytest.mark.parametrize("case", [(0, 7), (9, 0), (300, 120), (1, 1)])
+@pytest.mark.parametrize("case", [(0, 7), (9, 0), (300, 120), (1, 1), (60, 1500), (0, 900), (40, 2500, 40000)])
 def test_stage12_random_vs_oracle(dev, case):
+    """few / many lines and taps, taps only, lines only; the last case has coordinates beyond 2^14"""
     from orip import stages as S
     rng = np.random.default_rng(case[0] + case[1])
-    lines = _rand_polys(rng, case[0], lo=2, hi=12, span=3000, step=25, closed_p=0.0)
-    taps = _taps(rng.integers(0, 3000, (case[1], 2)))
+    span = case[2] if len(case) > 2 else 3000
+    lines = _rand_polys(rng, case[0], lo=2, hi=12, span=span, step=25, closed_p=0.0)
+    taps = _taps(rng.integers(0, span, (case[1], 2)))
     cfg = _cfgobj(dict(O.DEFAULTS))
     want = O.stage12(lines, taps, dict(O.DEFAULTS))
     got = S.plot_order(lines, taps, cfg, dev)
