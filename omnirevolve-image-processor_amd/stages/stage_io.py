@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))          # the package directory that holds `orip`
 
 
-RAW = bool(os.environ.get("ORIP_RAW_NPY"))
+RAW = os.environ.get("ORIP_RAW_NPY", "0") not in ("", "0")
 
 
 def _raw_ok(raw: str, ref: str) -> bool:
