@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--layers", type=int, default=8, help="colour layers (BASELINE: 8)")
     ap.add_argument("--upto", type=int, default=12, choices=[3, 12], help="3: stages 02 + 03 only (BASELINE config C2, use with --size 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, help="extra leg at N = 1: this many images in flight on the card, one context each (0 / 1: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,6 +211,42 @@ def main():
             roofline = {"kernel": "+".join(e["kernels"]), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": e["frac"], "traffic": traffic, "traffic_note": traffic_note, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
 
+    # ---- pipelined leg (N = 1 only, reported next to `value`, never as `value`): M images in flight, one context and one host thread each.
+    # A step alone leaves the card nearly idle while the walks of the heavy layers run; a second image fills that window.
+    pipelined = None
+    if world == 1 and args.upto == 12 and args.in_flight > 1:
+        import threading
+        try:
+            devs = [dev] + [Device(local_rank) for _ in range(args.in_flight - 1)]
+            for d in devs[1:]:
+                d.set_image(img); P.run_path_sharded(d, cfg, H, W, 0, 1)      # warm-up: allocations
+            for d in devs:
+                d.sync()
+            n_pl = max(2, args.steps)
+            errs = []
+
+            def work(d):
+                try:
+                    for _ in range(n_pl):
+                        P.run_path_sharded(d, cfg, H, W, 0, 1)
+                    d.sync()
+                except BaseException as ex:       # reported below
+                    errs.append(ex)
+            t2 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(d,)) for d in devs]
+            for x in th: x.start()
+            for x in th: x.join()
+            dtp = time.perf_counter() - t2
+            for d in devs[1:]:
+                d.close()
+            if errs:
+                raise errs[0]
+            pipelined = {"in_flight": len(devs), "steps": n_pl * len(devs), "ms_per_step": round(dtp * 1e3 / (n_pl * len(devs)), 2),
+                         "value": round((H * W / 1e6) * n_pl * len(devs) / dtp, 4), "unit": "Mpx/s",
+                         "note": "throughput with several images in flight on one card (one context and host thread per image); `value` above is one image at a time"}
+        except Exception as ex:
+            pipelined = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- CPU baseline legs (rank 0, N = 1 only): the oracle as a "port", bounded sample, single thread and layer threads
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -239,7 +276,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u8/i32 raster + f32/f64 geometry", "data": "synthetic",
             "config": {"workload": f"{W}x{H} BGR image, {K} colour layers, {stages}", "parallelism": f"layer-sharded x{args.gpus}",
                        "ops_last_step_rank0": int(n_ops), "exchange": (comm.kind if comm is not None else "none")},
-            "inclusive": inclusive, "roofline": roofline, "kernel_groups": groups_out, "cpu_baseline": cpu,
+            "inclusive": inclusive, "pipelined": pipelined, "roofline": roofline, "kernel_groups": groups_out, "cpu_baseline": cpu,
         }
         if world > 1 and n_vis < world:
             out["note"] = f"{world} ranks shared {n_vis} visible GPU(s) (gloo rehearsal): NOT a multi-GPU scaling point"
