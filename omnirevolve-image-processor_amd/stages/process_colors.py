@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-# process_colors.py -- drop-in for the reference tool of the same name (v1.1.1 outputs): labels.png / labels.npy / palette.json /
-# layer_<idx>_<name>.png from an image, adaptive (k-means) or palette mode.  Compute: liborip.so on the GPU (RGB k-means, nearest palette colour).
+# process_colors.py -- GPU drop-in for the reference's standalone label-map tool: same command line (input, -o, -m adaptive|palette, -n,
+# --palette, --edges-only) and the same files in the output directory (labels.png, labels.npy, palette.json, layer_<i>_<name>.png).
+# Compute: liborip.so (RGB k-means palette: orip_kmeans_fit_rgb; nearest palette colour per pixel: orip_assign_palette).
 import argparse
 import json
-from pathlib import Path
+import pathlib
+import sys
 
 import numpy as np
 
@@ -12,57 +14,55 @@ from orip import colors as PC
 from orip.device import Device
 
 
-def main():
-    ap = argparse.ArgumentParser(description="One-hot color layer generator with labels output")
-    ap.add_argument("input", help="Input image")
-    ap.add_argument("-o", "--output", default="layers", help="Output directory")
-    ap.add_argument("-m", "--mode", choices=["adaptive", "palette"], default="adaptive", help="adaptive: KMeans; palette: load palette JSON")
-    ap.add_argument("-n", "--colors", type=int, default=4, help="Number of colors for adaptive")
-    ap.add_argument("--palette", help="Palette JSON (from analyze_colors.py) for mode=palette")
-    ap.add_argument("--edges-only", action="store_true", help="Kept for pipeline compatibility (ignored)")
-    args = ap.parse_args()
-    out_dir = Path(args.output).absolute()
-    out_dir.mkdir(parents=True, exist_ok=True)
-    print("[process_colors] v1.1.1 (GPU)")
-    print(f"[process_colors] Input: {args.input}")
-    print(f"[process_colors] Output dir: {out_dir}")
-    bgr = _io.read_bgr(args.input)
-    if bgr is None:
-        raise ValueError(f"Cannot load image: {args.input}")
-    h, w = bgr.shape[:2]
-    print(f"[process_colors] Size: {w}x{h}")
-    dev = Device(0)
-    dev.set_image(bgr)
-    if args.mode == "palette":
-        if not args.palette:
+def _cli(argv):
+    p = argparse.ArgumentParser(description="strict one-hot colour layers + label map (GPU)")
+    p.add_argument("input")
+    p.add_argument("-o", "--output", default="layers")
+    p.add_argument("-m", "--mode", choices=("adaptive", "palette"), default="adaptive")
+    p.add_argument("-n", "--colors", type=int, default=4)
+    p.add_argument("--palette")
+    p.add_argument("--edges-only", action="store_true")          # accepted and ignored, as in the reference
+    return p.parse_args(argv)
+
+
+def _palette(opts, dev):
+    if opts.mode == "palette":
+        if not opts.palette:
             raise ValueError("Mode 'palette' requires --palette JSON")
-        palette_rgb, names = PC.palette_from_json(args.palette)
-        K = len(palette_rgb)
-        if args.colors and args.colors != K:
-            print(f"[WARN] --colors={args.colors} ignored; palette has {K} entries.")
-    else:
-        K = int(args.colors) if args.colors else 4
-        palette_rgb = PC.kmeans_palette(dev, K)
-        names = PC.default_color_names(K)
-    labels, counts = dev.assign_palette(palette_rgb)
-    total = labels.size
-    print("[process_colors] Class distribution:")
-    for i in range(K):
-        p = 100.0 * int(counts[i]) / total if total else 0.0
-        nm = names[i] if i < len(names) else f"color_{i}"
-        print(f"  [{i}] {nm:12s}  {tuple(int(v) for v in palette_rgb[i])}  pixels={int(counts[i]):8d}  {p:5.1f}%")
-    _io.write_png(str(out_dir / "labels.png"), labels)
-    np.save(str(out_dir / "labels.npy"), labels)
-    with open(out_dir / "palette.json", "w", encoding="utf-8") as f:
-        json.dump(PC.palette_dump(palette_rgb, names), f, indent=2)
-    for i in range(K):
-        nm = names[i] if i < len(names) else f"color_{i}"
-        _io.write_png(str(out_dir / f"layer_{i+1}_{nm}.png"), (labels == i).astype(np.uint8) * 255)
-    print(f"[process_colors] Done. {K} layer files written to: {out_dir}")
-    if args.edges_only:
-        print("[process_colors] NOTE: --edges-only is ignored here (kept for pipeline compatibility).")
-    dev.close()
+        rgb, names = PC.palette_from_json(opts.palette)
+        if opts.colors and opts.colors != len(rgb):
+            print(f"[WARN] --colors={opts.colors} ignored; palette has {len(rgb)} entries.")
+        return rgb, names
+    k = int(opts.colors) if opts.colors else 4
+    return PC.kmeans_palette(dev, k), PC.default_color_names(k)
+
+
+def run(opts) -> int:
+    out = pathlib.Path(opts.output).absolute()
+    out.mkdir(parents=True, exist_ok=True)
+    bgr = _io.read_bgr(opts.input)
+    if bgr is None:
+        raise ValueError(f"Cannot load image: {opts.input}")
+    print(f"[process_colors] {opts.input}: {bgr.shape[1]}x{bgr.shape[0]} -> {out}")
+    dev = Device(0)
+    try:
+        dev.set_image(bgr)
+        rgb, names = _palette(opts, dev)
+        labels, counts = dev.assign_palette(rgb)
+    finally:
+        dev.close()
+    name_of = lambda i: names[i] if i < len(names) else f"color_{i}"
+    share = 100.0 / max(1, labels.size)
+    for i in range(len(rgb)):
+        print(f"  [{i}] {name_of(i):12s}  {tuple(int(v) for v in rgb[i])}  pixels={int(counts[i]):8d}  {share * int(counts[i]):5.1f}%")
+    _io.write_png(str(out / "labels.png"), labels)
+    np.save(str(out / "labels.npy"), labels)
+    (out / "palette.json").write_text(json.dumps(PC.palette_dump(rgb, names), indent=2), encoding="utf-8")
+    for i in range(len(rgb)):
+        _io.write_png(str(out / f"layer_{i + 1}_{name_of(i)}.png"), np.where(labels == i, 255, 0).astype(np.uint8))
+    print(f"[process_colors] {len(rgb)} layers, labels.png / labels.npy / palette.json written")
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(run(_cli(sys.argv[1:])))
