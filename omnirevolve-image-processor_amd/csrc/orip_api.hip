@@ -50,7 +50,9 @@ extern "C" void orip_destroy(orip_ctx* c) {
         if (l.stream2) hipStreamDestroy(l.stream2);
         if (l.stream) hipStreamDestroy(l.stream);
     }
-    for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); }
+    for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); c->polys[s][l].vview.release(); }
+    for (auto& l : c->ln) for (auto& t : l.tp) { t.off.release(); t.pts.release(); t.vview.release(); }
+    for (auto& w : c->wstore) { w.log.release(); w.walk.release(); w.piece.release(); w.own.release(); }
     for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
     orip_contours_free(c);
@@ -105,6 +107,7 @@ extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, in
     ORIP_TRY(check_slot(c, slot, layer));
     DPolys& P = c->polys[slot][layer];
     if (P.n == 0) { off[0] = 0; return 0; }
+    ORIP_TRY(orip_polys_materialize(c, P));      // a walk-coded list (stages 04 / 05 / 07 of a resident chain) is expanded here, on request
     HIPC(c, hipMemcpyAsync(off, P.off.p, (size_t)(P.n + 1) * 8, hipMemcpyDeviceToHost, LN(c).stream));
     if (P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
@@ -122,6 +125,7 @@ extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const
     else HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
     if (total) HIPC(c, hipMemcpyAsync(P.pts.p, pts, (size_t)total * 8, hipMemcpyHostToDevice, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
+    P.set_explicit();
     P.n = n; P.total = total;      // the raster layer count (c->K) is NOT touched: list slots are addressed up to ORIP_MAX_LAYERS
     return 0;
 }

@@ -52,10 +52,31 @@ struct DBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-// Device polyline list: off int64[n+1], pts int32[2*total]
+// Device polyline list: off int64[n+1], pts int32[2*total].
+// A list can also be WALK-CODED (virt): its points are not stored but generated from the walk records stage 04 leaves for the layer
+// (WalkStore below: own points, bounce tails as (log range, cycle) pieces) through a view per polyline (walk, first point, length,
+// reversed) and an optional stage-05 scale -- see vsrc.h.  The walker re-walks the same pixels up to 4 * fg times, so
+// the explicit form of a heavy layer is 2.8e8 points (2.25 GB) for ~1e6 distinct ones; stages 05 / 07 / 08 read the coded form and the
+// explicit form only exists where somebody asks for it (orip_get_polys, a consumer that is not view-aware: orip_polys_materialize).
 struct DPolys {
     DBuf off, pts;
     int64_t n = 0, total = 0;
+    bool virt = false;          // walk-coded: `off` is valid, `pts` only when pts_ok
+    bool pts_ok = true;
+    DBuf vview;                 // VView[n]; unused when vident (polyline i = walk i, whole, forward)
+    bool vident = true;
+    int vlayer = 0;             // whose WalkStore
+    uint64_t vepoch = 0;        // WalkStore::epoch the list was built on: a later trace of the layer makes it stale
+    bool scaled = false; float sx = 1.f, sy = 1.f, dx = 0.f, dy = 0.f;     // _scale_one (05:82-96) applied on the fly
+    void set_explicit() { virt = false; pts_ok = true; }
+};
+// What stage 04 leaves per layer (raster04.hip: trace_finish) and every walk-coded list of the layer reads
+struct WalkStore {
+    DBuf log;                   // the trace's state log (walker.h: 4 words per entry)
+    DBuf walk, piece, own;      // VWalk[n], VPiece[...], int2 own points
+    int64_t n = 0;
+    int W = 0;
+    uint64_t epoch = 0;
 };
 struct DTaps {
     DBuf xy;  // int32[2*n]
@@ -120,6 +141,7 @@ struct orip_ctx {
     const void* mask_bits = nullptr;   // bit planes of `masks` left in tmpA by stage 02 (nullptr: not available); consumed by stage 03
     // vector state
     DPolys polys[ORIP_SLOT_COUNT][ORIP_MAX_LAYERS];
+    WalkStore wstore[ORIP_MAX_LAYERS];
     DTaps taps[2][ORIP_MAX_LAYERS];
     DBuf ops[ORIP_MAX_LAYERS];
     int64_t n_ops[ORIP_MAX_LAYERS] = {0};
@@ -165,3 +187,9 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // stage entry points implemented across the .hip files
 int orip_raster02_lab_tables(orip_ctx* c);
+// the per-layer stages without the closing stream wait (orip_layer_front chains them on the layer's stream)
+int orip_contours_layer_impl(orip_ctx* c, int layer, bool sync);
+int orip_scale_vectors_impl(orip_ctx* c, int layer, float sx, float sy, float dx, float dy, bool sync);
+int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync);
+// explicit points of a walk-coded list (no-op for explicit lists); on the calling lane's stream, not synchronised (vector.hip)
+int orip_polys_materialize(orip_ctx* c, DPolys& P);

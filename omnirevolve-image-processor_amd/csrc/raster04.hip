@@ -143,15 +143,44 @@ __global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, int layer, const
         write_chunk(A, layer, kept_slots, kept_off, n_kept, p0, p1);
     }
 }
-// lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here
-__global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept) {
+// lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here.
+// opc: own points (n_own + 1) << 32 | tail pieces of a kept walk (one scan sizes both arrays of the walk-coded form)
+__global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept, unsigned long long* __restrict__ opc) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         WalkInfo w = A.winfo[slot0 + i];
         if (w.flags & 2u) { walk_close_tail(A, PlainReader(), slot0 + i, w); A.winfo[slot0 + i] = w; }
         lens[i] = w.len_kept; kept[i] = w.len_kept ? 1u : 0u;
+        unsigned long long o = 0;
+        if (w.len_kept) o = ((unsigned long long)(w.n_own + 1u) << 32) | vwalk_pieces(A.logbuf, PlainReader(), w, [](unsigned, unsigned, unsigned, unsigned) {});
+        opc[i] = o;
     }
-    if (i == n) { lens[i] = 0; kept[i] = 0; }
+    if (i == n) { lens[i] = 0; kept[i] = 0; opc[i] = 0; }
+}
+// totals of the three scans in one row: points, paths, own points, pieces
+__global__ void k_walk_totals(const unsigned long long* __restrict__ pts_off, const unsigned* __restrict__ path_off, const unsigned long long* __restrict__ opc_off, unsigned n, unsigned long long* __restrict__ out) {
+    out[0] = pts_off[n]; out[1] = path_off[n]; out[2] = opc_off[n] >> 32; out[3] = opc_off[n] & 0xffffffffull;
+}
+// the walk-coded form of the layer's contours: one VWalk per kept walk (path order = slot order), its tail pieces, its offset in the list
+__global__ __launch_bounds__(256) void k_vwalk_fill(WalkArgs A, unsigned slot0, unsigned n, const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off,
+                                                     const unsigned long long* __restrict__ pts_off, const unsigned long long* __restrict__ opc_off, unsigned log_shift,
+                                                     VWalk* __restrict__ vw, VPiece* __restrict__ vp, unsigned* __restrict__ kept_slots, int64_t* __restrict__ off) {
+    unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i == n) off[path_off[n]] = (int64_t)pts_off[n];
+    if (i >= n || !kept[i]) return;
+    const WalkInfo w = A.winfo[slot0 + i];
+    VWalk v; v.own_off = (unsigned)(opc_off[i] >> 32); v.n_own = w.n_own; v.piece_off = (unsigned)(opc_off[i] & 0xffffffffull); v.len = w.len_kept; v.flags = w.flags & 1u; v.pad0 = v.pad1 = 0;
+    VPiece* mine = vp + v.piece_off;
+    v.n_piece = vwalk_pieces(A.logbuf, PlainReader(), w, [&](unsigned j, unsigned u0, unsigned ent, unsigned lam) { VPiece q; q.u0 = u0; q.ent = ent - log_shift; q.lam = lam; q.pad = 0; mine[j] = q; });
+    const unsigned pi = path_off[i];
+    vw[pi] = v; kept_slots[pi] = slot0 + i; off[pi] = (int64_t)pts_off[i];
+}
+// own points of the kept walks, one wavefront per chunk
+__global__ __launch_bounds__(64) void k_vown(WalkArgs A, const unsigned* __restrict__ kept_slots, const VWalk* __restrict__ vw, unsigned n_kept, int2* __restrict__ own, unsigned total, unsigned chunk) {
+    for (unsigned long long ci = blockIdx.x; ci * chunk < total; ci += gridDim.x) {
+        const unsigned q0 = (unsigned)(ci * chunk), q1 = q0 + chunk < total ? q0 + chunk : total;
+        own_chunk(A, kept_slots, vw, n_kept, own, q0, q1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,7 +414,7 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     for (int l = 0; l < K; l++) {
         DPolys& P = c->polys[ORIP_SLOT_CONTOURS][l];
-        P.n = 0; P.total = 0;
+        P.n = 0; P.total = 0; P.set_explicit();
         HIPC(c, P.off.ensure(8)); HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
     }
     R.M = M; R.NC = 0;
@@ -461,10 +490,12 @@ static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F) {
     const size_t plane = (size_t)R.A.plane;
     if ((uint64_t)F * R.M + (uint64_t)256 * R.NC + 64 >= 0xffffffffull) ORIP_FAIL(c, "skeleton too large for the walk logs (factor %u)", F);
     const size_t nlog = (size_t)F * Ml + (size_t)64 * NCl + 8, nstep = (size_t)F * Ml + (size_t)256 * NCl + 8;
-    HIPC(c, LN(c).vtmp[7].ensure(nlog * 16 + 64));
+    WalkStore& WS = c->wstore[layer];
+    WS.epoch++; WS.n = 0;                              // walk-coded lists built on the previous trace of this layer are stale from here on
+    HIPC(c, WS.log.ensure(nlog * 16 + 64));
     HIPC(c, LN(c).vtmp[9].ensure(nstep + 64));
     WalkArgs A = R.A;
-    A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)F * b0 + (size_t)64 * c0);
+    A.logbuf = WS.log.as<unsigned>() - 4 * ((size_t)F * b0 + (size_t)64 * c0);
     A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)F * b0 + (size_t)256 * c0);
     A.cap_factor = F; A.comp_order = R.order + c0; A.nc = NCl;
     int* d_over = LN(c).flags.as<int>() + 20; A.overflow = d_over;
@@ -514,56 +545,67 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     }
     // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
     const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
-    HIPC(c, LN(c).vtmp[4].ensure((size_t)(nslots + 1) * (8 + 8 + 8 + 4 + 4) + (size_t)nslots * 4 + 256));
-    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + (nslots + 1); unsigned long long* kept_off = pts_off + (nslots + 1);
-    unsigned* kept = (unsigned*)(kept_off + (nslots + 1)); unsigned* path_off = kept + (nslots + 1); unsigned* kept_slots = path_off + (nslots + 1);
-    {
-        WalkArgs A = R.A;                    // the layer's logs as the trace addressed them (walk_close_tail follows the recorded trajectories)
-        A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)R.F[layer] * b0 + (size_t)64 * c0);
-        A.cap_factor = R.F[layer];
-        hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, lens, kept);
-    }
-    ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, (size_t)nslots + 1, LN(c).tmpF));
-    ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, (size_t)nslots + 1, LN(c).tmpF));
-    unsigned long long h_pts = 0; unsigned h_paths = 0;
-    HIPC(c, hipMemcpyAsync(&h_pts, pts_off + nslots, 8, hipMemcpyDeviceToHost, LN(c).stream));
-    HIPC(c, hipMemcpyAsync(&h_paths, path_off + nslots, 4, hipMemcpyDeviceToHost, LN(c).stream));
+    const size_t ns1 = (size_t)nslots + 1;
+    HIPC(c, LN(c).vtmp[4].ensure(ns1 * (8 + 8 + 8 + 8 + 4 + 4) + 256));
+    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + ns1; unsigned long long* opc = pts_off + ns1; unsigned long long* opc_off = opc + ns1;
+    unsigned* kept = (unsigned*)(opc_off + ns1); unsigned* path_off = kept + ns1;
+    WalkStore& WS = c->wstore[layer];
+    const unsigned log_shift = (unsigned)((size_t)R.F[layer] * b0 + (size_t)64 * c0);
+    WalkArgs A = R.A;                        // the layer's logs as the trace addressed them (walk_close_tail / vwalk_pieces follow the recorded trajectories)
+    A.logbuf = WS.log.as<unsigned>() - 4 * (size_t)log_shift;
+    A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
+    A.cap_factor = R.F[layer];
+    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, lens, kept, opc);
+    ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, ns1, LN(c).tmpF));
+    ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, ns1, LN(c).tmpF));
+    ORIP_TRY(excl_scan<unsigned long long>(c, opc, opc_off, ns1, LN(c).tmpF));
+    unsigned long long* d_tot = LN(c).flags.as<unsigned long long>() + 120;       // bytes 960..992 of the lane's flag page
+    hipLaunchKernelGGL(k_walk_totals, dim3(1), dim3(1), 0, LN(c).stream, pts_off, path_off, opc_off, nslots, d_tot);
+    unsigned long long h_tot[4] = {0, 0, 0, 0};
+    HIPC(c, hipMemcpyAsync(h_tot, d_tot, 32, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
+    const unsigned long long h_pts = h_tot[0]; const unsigned h_paths = (unsigned)h_tot[1], h_own = (unsigned)h_tot[2], h_pieces = (unsigned)h_tot[3];
+    if (h_tot[2] > 0xfffffff0ull) ORIP_FAIL(c, "layer %d: too many own points for the walk-coded form", layer);
+    // ---- the contours of the layer in walk-coded form (walker.h): nothing is expanded here
     DPolys& P = c->polys[ORIP_SLOT_CONTOURS][layer];
     P.total = (int64_t)h_pts; P.n = (int64_t)h_paths;
-    HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
+    P.virt = true; P.pts_ok = false; P.vident = true; P.vlayer = layer; P.vepoch = WS.epoch; P.scaled = false;
     HIPC(c, P.off.ensure((size_t)(P.n + 1) * 8 + 64));
-    HIPC(c, hipMemsetAsync(P.off.p, 0, 8, LN(c).stream));
+    HIPC(c, WS.walk.ensure((size_t)std::max(h_paths, 1u) * sizeof(VWalk) + 64));
+    HIPC(c, WS.piece.ensure((size_t)std::max(h_pieces, 1u) * sizeof(VPiece) + 64));
+    HIPC(c, WS.own.ensure((size_t)std::max(h_own, 1u) * 8 + 64));
+    HIPC(c, LN(c).vtmp[5].ensure((size_t)std::max(h_paths, 1u) * 4 + 64));
+    unsigned* kept_slots = LN(c).vtmp[5].as<unsigned>();
+    WS.n = P.n; WS.W = R.A.W;
+    hipLaunchKernelGGL(k_vwalk_fill, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, kept, path_off, pts_off, opc_off, log_shift,
+                       WS.walk.as<VWalk>(), WS.piece.as<VPiece>(), kept_slots, P.off.as<int64_t>());
     if (h_paths) {
-        WalkArgs A = R.A;
-        A.logbuf = LN(c).vtmp[7].as<unsigned>() - 4 * ((size_t)R.F[layer] * b0 + (size_t)64 * c0);
-        A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
-        A.cap_factor = R.F[layer];
-        A.pts_off = pts_off - sl0; A.path_off = path_off - sl0;          // indexed by global slot
-        A.layer_pts_base[layer] = 0; A.layer_path_base[layer] = 0;
-        A.pts[layer] = P.pts.as<int32_t>(); A.off[layer] = P.off.as<int64_t>();
-        hipLaunchKernelGGL(k_kept_slots_base, dim3(cdiv(nslots, 256)), block, 0, LN(c).stream, kept, path_off, pts_off, nslots, sl0, kept_slots, kept_off);
         ProfScope ps(c, "k_write_walks");
-        const unsigned chunk = 4096;
-        hipLaunchKernelGGL(k_write_walks, dim3((unsigned)std::min<unsigned long long>((h_pts + chunk - 1) / chunk, 262144ull)), dim3(64), 0, LN(c).stream, A, layer, kept_slots, kept_off, h_paths, h_pts, chunk);
+        const unsigned chunk = 2048;
+        hipLaunchKernelGGL(k_vown, dim3((unsigned)std::min<unsigned long long>(((unsigned long long)h_own + chunk - 1) / chunk, 262144ull)), dim3(64), 0, LN(c).stream, A, kept_slots, WS.walk.as<VWalk>(), h_paths,
+                           WS.own.as<int2>(), h_own, chunk);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(LN(c).stream));
     R.launched[layer] = false;
     return 0;
 }
 
 // Contours of one layer (after orip_contours_prepare).  Runs on the layer's own lane, so different layers can be traced from
 // different host threads at the same time and a finished layer can move on to stages 05-08 while others are still walking.
-extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
-    orip_enter(c);
+int orip_contours_layer_impl(orip_ctx* c, int layer, bool sync) {
     Prep04* R = static_cast<Prep04*>(c->prep04);
     if (!R || !R->ready) ORIP_FAIL(c, "orip_contours_prepare has not run");
     if (layer < 0 || layer >= R->K) ORIP_FAIL(c, "bad layer %d (prepared for %d layers)", layer, R->K);
     if (R->M == 0 || R->layer_first[layer] == R->layer_first[layer + 1]) return 0;
     ORIP_LANE(c, layer + 1);
     ORIP_TRY(trace_launch(c, *R, layer, 64));
-    return trace_finish(c, *R, layer);
+    ORIP_TRY(trace_finish(c, *R, layer));
+    if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
+    return 0;
+}
+extern "C" int orip_contours_layer(orip_ctx* c, int layer) {
+    orip_enter(c);
+    return orip_contours_layer_impl(c, layer, true);
 }
 
 extern "C" int orip_find_contours(orip_ctx* c) {
@@ -573,7 +615,7 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     if (R.M == 0) return 0;
     // every layer's trace is enqueued on its own stream first, so the long serial walks of all layers overlap
     for (int l = 0; l < R.K; l++) if (R.layer_first[l] != R.layer_first[l + 1]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
-    for (int l = 0; l < R.K; l++) if (R.launched[l]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_finish(c, R, l)); }
+    for (int l = 0; l < R.K; l++) if (R.launched[l]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_finish(c, R, l)); HIPC(c, hipStreamSynchronize(LN(c).stream)); }
     return 0;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include "orip_ctx.h"
 #include "vec_serial.h"
+#include "vsrc.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 
@@ -46,27 +47,52 @@ struct PolyFeat {
 };
 
 #define ORIP_LONG_POLY 512
+// ---- where a list's points come from (vsrc.h): explicit array or the layer's walk records ----
+static inline ESrc esrc_of(const DPolys& P) { return ESrc{P.off.as<int64_t>(), reinterpret_cast<const int2*>(P.pts.p)}; }
+static int vsrc_of(orip_ctx* c, const DPolys& P, VSrc& out) {
+    const WalkStore& WS = c->wstore[P.vlayer];
+    if (P.vepoch != WS.epoch) ORIP_FAIL(c, "the walk records of layer %d this list was built on have been replaced by a newer orip_contours_layer", P.vlayer);
+    out.off = P.off.as<int64_t>(); out.view = P.vident ? nullptr : P.vview.as<VView>(); out.walk = WS.walk.as<VWalk>();
+    out.g.piece = WS.piece.as<VPiece>(); out.g.own = WS.own.as<int2>(); out.g.logw = WS.log.as<unsigned>();
+    out.g.W = (unsigned)WS.W; out.g.wmagic = ((1ull << 40) + (unsigned long long)WS.W - 1ull) / (unsigned long long)WS.W;
+    out.g.scaled = P.scaled ? 1 : 0; out.g.sx = P.sx; out.g.sy = P.sy; out.g.dx = P.dx; out.g.dy = P.dy;
+    return 0;
+}
+static inline bool is_coded(const DPolys& P) { return P.virt && !P.pts_ok; }
+// runs BODY once with SRC bound to the list's point source (VSrc for a walk-coded list whose points are not expanded, else ESrc)
+#define ORIP_WITH_SRC(c, P, SRC, BODY)                                                         \
+    do {                                                                                       \
+        if (is_coded(P)) { VSrc SRC; ORIP_TRY(vsrc_of(c, P, SRC)); BODY }                      \
+        else { const ESrc SRC = esrc_of(P); BODY }                                             \
+    } while (0)
+template <class Cur> struct CurPt {
+    const Cur& c;
+    __device__ __forceinline__ vs::IPt operator()(int64_t i) const { const int2 p = c.at(i); return vs::IPt{p.x, p.y}; }
+};
+
 // what: bit0 perimeter KIND0, bit1 perimeter KIND1 (hypot), bit2 arcLength closed, bit3 arcLength open, bit4 open view (_ensure_open)
-__global__ __launch_bounds__(128) void k_poly_features(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
-                                                        PolyFeat* __restrict__ out) {
+template <class Src>
+__global__ __launch_bounds__(128) void k_poly_features(Src src, int64_t n_polys, int what, PolyFeat* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_polys) return;
-    const int32_t* p = pts + 2 * off[i];
-    int64_t n = off[i + 1] - off[i];
+    const auto cu = src.cur(i);
+    int64_t n = src.len(i);
     PolyFeat f;
-    f.closed = (n >= 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) ? 1 : 0;
-    if ((what & 16) && f.closed) n -= 1;
+    const int2 pf = cu.at(0); int2 pl = n >= 1 ? cu.at(n - 1) : pf;
+    f.closed = (n >= 2 && pf.x == pl.x && pf.y == pl.y) ? 1 : 0;
+    if ((what & 16) && f.closed) { n -= 1; pl = cu.at(n - 1); }
     f.n = n;
-    f.sx = p[0]; f.sy = p[1]; f.ex = p[2 * (n - 1)]; f.ey = p[2 * (n - 1) + 1];
-    f.per = 0.f; f.arc = 0.0; f.x0 = f.x1 = p[0]; f.y0 = f.y1 = p[1];
+    f.sx = pf.x; f.sy = pf.y; f.ex = pl.x; f.ey = pl.y;
+    f.per = 0.f; f.arc = 0.0; f.x0 = f.x1 = pf.x; f.y0 = f.y1 = pf.y;
     if (n > ORIP_LONG_POLY) { out[i] = f; return; }      // bbox / sums of long polylines: k_poly_features_long (one block each)
-    int32_t x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1];
-    for (int64_t k = 1; k < n; k++) { int32_t x = p[2 * k], y = p[2 * k + 1]; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+    int32_t x0 = pf.x, x1 = pf.x, y0 = pf.y, y1 = pf.y;
+    for (int64_t k = 1; k < n; k++) { const int2 q = cu.at(k); x0 = min(x0, q.x); x1 = max(x1, q.x); y0 = min(y0, q.y); y1 = max(y1, q.y); }
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
-    if (what & 1) f.per = vs::pairwise_seglen_sum<0>(p, n);
-    if (what & 2) f.per = vs::pairwise_seglen_sum<1>(p, n);
-    if (what & 4) f.arc = vs::arc_length(p, n, true);
-    if (what & 8) f.arc = vs::arc_length(p, n, false);
+    const CurPt<decltype(cu)> pt{cu};
+    if (what & 1) f.per = vs::pairwise_seglen_sum_p<0>(pt, n);
+    if (what & 2) f.per = vs::pairwise_seglen_sum_p<1>(pt, n);
+    if (what & 4) f.arc = vs::arc_length_p(pt, n, true);
+    if (what & 8) f.arc = vs::arc_length_p(pt, n, false);
     out[i] = f;
 }
 
@@ -110,7 +136,8 @@ __global__ __launch_bounds__(256) void k_len_keys(const int64_t* __restrict__ of
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) { int64_t m = off[i + 1] - off[i]; key[i] = (unsigned)(m > 0xffffffffLL ? 0xffffffffLL : m); val[i] = (unsigned)i; }
 }
-__global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, int what,
+template <class Src>
+__global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_polys, int what,
                                                              PolyFeat* __restrict__ out, float* __restrict__ leafbuf, const unsigned* __restrict__ order) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
@@ -121,20 +148,20 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
         PolyFeat f = out[i];
         const int64_t n = f.n;                     // already the open view when requested
         if (n <= ORIP_LONG_POLY) continue;         // uniform for the block
-        const int32_t* p = pts + 2 * off[i];
+        const auto cu = src.cur(i);
+        auto P2 = [&](int64_t k) { return cu.at(k); };
         const int tid = threadIdx.x;
-        int x0 = p[0], x1 = p[0], y0 = p[1], y1 = p[1]; double arc = 0.0;
+        int x0 = f.sx, x1 = f.sx, y0 = f.sy, y1 = f.sy; double arc = 0.0;
         const bool closed_arc = (what & 4) != 0, any_arc = (what & 12) != 0;
-        const int2* P2 = reinterpret_cast<const int2*>(p);
         if (!any_arc) {
             // bounding box only: four independent 8-byte loads per turn keep the memory pipeline busy (the loop is latency-bound otherwise)
             int64_t k = tid;
             for (; k + 768 < n; k += 1024) {
-                const int2 a = P2[k], b = P2[k + 256], cc = P2[k + 512], d = P2[k + 768];
+                const int2 a = P2(k), b = P2(k + 256), cc = P2(k + 512), d = P2(k + 768);
                 x0 = min(min(x0, a.x), min(min(b.x, cc.x), d.x)); x1 = max(max(x1, a.x), max(max(b.x, cc.x), d.x));
                 y0 = min(min(y0, a.y), min(min(b.y, cc.y), d.y)); y1 = max(max(y1, a.y), max(max(b.y, cc.y), d.y));
             }
-            for (; k < n; k += 256) { const int2 a = P2[k]; x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
+            for (; k < n; k += 256) { const int2 a = P2(k); x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
         } else {
             // arc length next to the bounding box: the same four-loads-in-flight shape; a thread adds its terms in the order of its k
             auto seg = [&](int64_t k, const int2 a, const int2 b) {       // b: predecessor of point k
@@ -145,11 +172,11 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
             auto pred = [&](int64_t k) -> int64_t { return k == 0 ? (closed_arc ? n - 1 : 0) : k - 1; };
             int64_t k = tid;
             for (; k + 768 < n; k += 1024) {
-                const int2 a0 = P2[k], a1 = P2[k + 256], a2 = P2[k + 512], a3 = P2[k + 768];
-                const int2 b0 = P2[pred(k)], b1 = P2[k + 255], b2 = P2[k + 511], b3 = P2[k + 767];
+                const int2 a0 = P2(k), a1 = P2(k + 256), a2 = P2(k + 512), a3 = P2(k + 768);
+                const int2 b0 = P2(pred(k)), b1 = P2(k + 255), b2 = P2(k + 511), b3 = P2(k + 767);
                 seg(k, a0, b0); seg(k + 256, a1, b1); seg(k + 512, a2, b2); seg(k + 768, a3, b3);
             }
-            for (; k < n; k += 256) seg(k, P2[k], P2[pred(k)]);
+            for (; k < n; k += 256) seg(k, P2(k), P2(pred(k)));
         }
         rx0[tid] = x0; rx1[tid] = x1; ry0[tid] = y0; ry1[tid] = y1; rarc[tid] = arc;
         __syncthreads();
@@ -160,7 +187,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
         float per = 0.f;
         if (what & 3) {
             const int64_t ns = n - 1;               // number of segments
-            float* ls = leafbuf + (off[i] >> 6) + 2 * i;
+            float* ls = leafbuf + (src.off[i] >> 6) + 2 * i;
             const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group and turn
             // a turn covers the 32 multiples of 64 in [r0, r0 + 2048): the leaves that own them lie inside [r0 - 63, r0 + 2047 + 128],
             // so that stretch of points is staged in LDS by all threads (independent coalesced loads) and the groups sum from there
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
             auto request = [&](int64_t r0) {
                 const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);
 #pragma unroll
-                for (int u = 0; u < 9; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2[q] : make_int2(0, 0); }
+                for (int u = 0; u < 9; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2(q) : make_int2(0, 0); }
             };
             request(0);
             for (int64_t r0 = 0; r0 < ns; r0 += 32 * 64) {
@@ -223,20 +250,25 @@ __global__ __launch_bounds__(256) void k_poly_features_long(const int64_t* __res
     }
 }
 // features of every polyline of a list: short ones one lane each, long ones one block each
-static int vfeatures(orip_ctx* c, const int64_t* off, const int32_t* pts, int64_t n, int64_t total, int what, PolyFeat* feat) {
+template <class Src>
+static int vfeatures_src(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_poly_features, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, off, pts, n, what, feat);
+    hipLaunchKernelGGL(k_poly_features<Src>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src, n, what, feat);
     if (total > ORIP_LONG_POLY) {
         const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
         HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) + (size_t)n * 16 + 64));
         float* leafbuf = LN(c).vtmp[11].as<float>();
         unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
-        hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, off, n, kin, vin);
+        hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
         ProfScope ps(c, "k_poly_features_long");
-        hipLaunchKernelGGL(k_poly_features_long, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, off, pts, n, what, feat, leafbuf, vout);
+        hipLaunchKernelGGL(k_poly_features_long<Src>, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout);
     }
     HIPC(c, hipGetLastError());
+    return 0;
+}
+static int vfeatures(orip_ctx* c, const DPolys& P, int what, PolyFeat* feat) {
+    ORIP_WITH_SRC(c, P, src, { ORIP_TRY(vfeatures_src(c, src, P.n, P.total, what, feat)); });
     return 0;
 }
 
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e
 }
 
 // ---- descriptor-driven gather: output polyline k = src points [begin[k], begin[k]+len[k]) (reversed if rev[k]) ----
-struct GatherDesc { int64_t begin; int64_t len; int32_t rev; int32_t pad; };
+struct GatherDesc { int64_t begin; int64_t len; int32_t rev; int32_t src; };     // src: index of the source polyline (walk-coded sources are addressed by polyline, not by point)
 __global__ __launch_bounds__(256) void k_gather_lens(const GatherDesc* __restrict__ d, int64_t n, int64_t* __restrict__ lens) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) lens[i] = d[i].len;
@@ -511,7 +543,7 @@ __global__ __launch_bounds__(256) void k_gather_pts(const GatherDesc* __restrict
 }
 // Builds dst (DPolys) from descriptors (device array of n descs).  lens/off scratch in ctx->tmpE.
 static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* src, DPolys& dst) {
-    dst.n = n; dst.total = 0;
+    dst.n = n; dst.total = 0; dst.set_explicit();
     HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
     if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 8 + 64));
@@ -525,6 +557,57 @@ static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* s
     HIPC(c, hipGetLastError());
     return 0;
 }
+// The same selection over a walk-coded source moves no points: output polyline k is a VIEW (walker.h) of the walk behind source
+// polyline d[k].src -- its first d[k].len points, reversed if d[k].rev -- composed with the view the source polyline already is.
+__global__ __launch_bounds__(256) void k_view_select(const GatherDesc* __restrict__ d, int64_t n, const VView* __restrict__ sview, const VWalk* __restrict__ walk,
+                                                      VView* __restrict__ out, int64_t* __restrict__ lens) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k == n) lens[k] = 0;
+    if (k >= n) return;
+    const GatherDesc g = d[k];
+    VView s;
+    if (sview) s = sview[g.src]; else { s.wid = (unsigned)g.src; s.first = 0u; s.len = walk[g.src].len; s.rev = 0u; }
+    VView o; o.wid = s.wid; o.len = (unsigned)g.len; o.rev = s.rev ^ (g.rev ? 1u : 0u);
+    o.first = s.rev ? s.first + s.len - (unsigned)g.len : s.first;
+    out[k] = o; lens[k] = g.len;
+}
+static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst) {
+    VSrc vs_; ORIP_TRY(vsrc_of(c, src, vs_));
+    dst.n = n; dst.total = 0;
+    dst.virt = true; dst.pts_ok = false; dst.vident = false; dst.vlayer = src.vlayer; dst.vepoch = src.vepoch;
+    dst.scaled = src.scaled; dst.sx = src.sx; dst.sy = src.sy; dst.dx = src.dx; dst.dy = src.dy;
+    HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
+    if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
+    HIPC(c, dst.vview.ensure((size_t)n * sizeof(VView) + 64));
+    HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 8 + 64));
+    hipLaunchKernelGGL(k_view_select, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, d, n, vs_.view, vs_.walk, dst.vview.as<VView>(), LN(c).tmpE.as<int64_t>());
+    ORIP_TRY(vscan_excl<int64_t>(c, LN(c).tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
+    int64_t total = 0;
+    ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
+    dst.total = total;
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+// selection out of a list of either kind
+static int vgather_list(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst) {
+    if (is_coded(src)) return vgather_views(c, d, n, src, dst);
+    return vgather(c, d, n, src.pts.as<int32_t>(), dst);
+}
+// explicit points of a list of either kind: 4096 consecutive output points per block (as k_gather_pts)
+template <class Src>
+__global__ __launch_bounds__(256) void k_expand_pts(Src src, int64_t n, int2* __restrict__ dst, int64_t total) {
+    const int64_t start = (int64_t)blockIdx.x * 4096;
+    if (start >= total) return;
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (src.off[mid] <= start) lo = mid; else hi = mid - 1; }
+    int64_t k = lo, kc = -1;
+    auto cu = src.cur(k);
+    for (int64_t idx = start + threadIdx.x; idx < min(total, start + 4096); idx += 256) {
+        while (src.off[k + 1] <= idx) k++;
+        if (k != kc) { cu = src.cur(k); kc = k; }
+        dst[idx] = cu.at(idx - src.off[k]);
+    }
+}
 
 // order/flip -> descriptors over a source list
 __global__ __launch_bounds__(256) void k_desc_from_order(const int64_t* __restrict__ off, const int32_t* __restrict__ order, const uint8_t* __restrict__ flips,
@@ -532,7 +615,7 @@ __global__ __launch_bounds__(256) void k_desc_from_order(const int64_t* __restri
     int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     int i = order ? order[k] : (int)k;
-    GatherDesc g; g.begin = off[i]; g.len = open_view ? feat[i].n : (off[i + 1] - off[i]); g.rev = flips ? flips[k] : 0; g.pad = 0;
+    GatherDesc g; g.begin = off[i]; g.len = open_view ? feat[i].n : (off[i + 1] - off[i]); g.rev = flips ? flips[k] : 0; g.src = i;
     d[k] = g;
 }
 
@@ -552,14 +635,14 @@ __global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict
     }
     if (threadIdx.x == 0) *out = bi[0];
 }
-__global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restrict__ f, int64_t n, int rule07, const int64_t* __restrict__ off,
-                                                         const int32_t* __restrict__ pts, NNEnds* __restrict__ e) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restrict__ f, int64_t n, int rule07, Src src, NNEnds* __restrict__ e) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     NNEnds q; q.sx = f[i].sx; q.sy = f[i].sy; q.ex = f[i].ex; q.ey = f[i].ey; q.closed = f[i].closed;
     if (rule07 && f[i].closed) {   // _ends (07:12-17): a closed contour ends at its second-to-last point
-        int64_t m = off[i + 1] - off[i];
-        if (m > 1) { const int32_t* p = pts + 2 * off[i]; q.ex = p[2 * (m - 2)]; q.ey = p[2 * (m - 2) + 1]; }
+        int64_t m = src.len(i);
+        if (m > 1) { const int2 p = src.cur(i).at(m - 2); q.ex = p.x; q.ey = p.y; }
     }
     e[i] = q;
 }
@@ -718,7 +801,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
 // Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
 static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int64_t n = src.n;
-    if (n == 0) { dst.n = 0; dst.total = 0; HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
+    if (n == 0) { dst.n = 0; dst.total = 0; dst.set_explicit(); HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     if (n > 0x7fffffff) ORIP_FAIL(c, "too many polylines");
     HIPC(c, LN(c).vtmp[6].ensure((size_t)n * (sizeof(PolyFeat) + sizeof(NNEnds) + sizeof(GatherDesc) + 4 + 2) + 256));
     PolyFeat* feat = LN(c).vtmp[6].as<PolyFeat>();
@@ -727,8 +810,8 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     int32_t* order = (int32_t*)(desc + n);
     uint8_t* flips = (uint8_t*)(order + n); uint8_t* used = flips + n;
     int what = kind == 7 ? 4 : (kind == 8 ? 1 : 8);
-    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, what, feat));
-    hipLaunchKernelGGL(k_ends_from_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, src.off.as<int64_t>(), src.pts.as<int32_t>(), ends);
+    ORIP_TRY(vfeatures(c, src, what, feat));
+    ORIP_WITH_SRC(c, src, ps, { hipLaunchKernelGGL(k_ends_from_feat<decltype(ps)>, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, ps, ends); });
     int* d_seed = LN(c).flags.as<int>() + 32;
     HIPC(c, hipMemsetAsync(d_seed + 1, 0, 4, LN(c).stream));
     hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
@@ -764,7 +847,7 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
     }
     hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
     HIPC(c, hipGetLastError());
-    return vgather(c, desc, n, src.pts.as<int32_t>(), dst);
+    return vgather_list(c, desc, n, src, dst);
 }
 
 }  // namespace

@@ -14,21 +14,29 @@
 namespace vs {
 
 // ---- exact float helpers (no contraction: the TU is built with -ffp-contract=off) ----
-ORIP_HD inline float seg_len_f32(const int32_t* xy, int64_t i) {       // np.linalg.norm(p[i+1]-p[i]) in float32 (08:25-28)
-    float dx = (float)xy[2 * i + 2] - (float)xy[2 * i], dy = (float)xy[2 * i + 3] - (float)xy[2 * i + 1];
+// Points come through a getter pt(i) -> IPt, so the same arithmetic runs over an int32 x,y array (XYPtr) and over the cursor of a
+// walk-coded list (vsrc.h).
+struct IPt { int32_t x, y; };
+struct XYPtr { const int32_t* xy; ORIP_HD IPt operator()(int64_t i) const { return IPt{xy[2 * i], xy[2 * i + 1]}; } };
+template <class PT> ORIP_HD inline float seg_len_f32_p(const PT& pt, int64_t i) {       // np.linalg.norm(p[i+1]-p[i]) in float32 (08:25-28)
+    const IPt a = pt(i), b = pt(i + 1);
+    float dx = (float)b.x - (float)a.x, dy = (float)b.y - (float)a.y;
     float qx = dx * dx, qy = dy * dy;
     return sqrtf(qx + qy);
 }
-ORIP_HD inline float seg_hypot_f32(const int32_t* xy, int64_t i) {     // np.hypot on float32 (12:71-76), correctly rounded
-    float dx = (float)xy[2 * i + 2] - (float)xy[2 * i], dy = (float)xy[2 * i + 3] - (float)xy[2 * i + 1];
+template <class PT> ORIP_HD inline float seg_hypot_f32_p(const PT& pt, int64_t i) {     // np.hypot on float32 (12:71-76), correctly rounded
+    const IPt a = pt(i), b = pt(i + 1);
+    float dx = (float)b.x - (float)a.x, dy = (float)b.y - (float)a.y;
     return (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
 }
+ORIP_HD inline float seg_len_f32(const int32_t* xy, int64_t i) { return seg_len_f32_p(XYPtr{xy}, i); }
+ORIP_HD inline float seg_hypot_f32(const int32_t* xy, int64_t i) { return seg_hypot_f32_p(XYPtr{xy}, i); }
 ORIP_HD inline long long round_half_even(double v) { return (long long)rint(v); }
 
 // numpy float32 pairwise summation of the n segment lengths of a polyline (ndarray.sum()); KIND 0: seg_len_f32, 1: seg_hypot_f32
-template <int KIND>
-ORIP_HD inline float pairwise_leaf(const int32_t* xy, int64_t s, int64_t n) {
-    auto el = [&](int64_t i) { return KIND == 0 ? seg_len_f32(xy, s + i) : seg_hypot_f32(xy, s + i); };
+template <int KIND, class PT>
+ORIP_HD inline float pairwise_leaf_p(const PT& pt, int64_t s, int64_t n) {
+    auto el = [&](int64_t i) { return KIND == 0 ? seg_len_f32_p(pt, s + i) : seg_hypot_f32_p(pt, s + i); };
     if (n < 8) { float r = 0.f; for (int64_t i = 0; i < n; i++) r += el(i); return r; }
     float r0 = el(0), r1 = el(1), r2 = el(2), r3 = el(3), r4 = el(4), r5 = el(5), r6 = el(6), r7 = el(7);
     int64_t i;
@@ -37,18 +45,18 @@ ORIP_HD inline float pairwise_leaf(const int32_t* xy, int64_t s, int64_t n) {
     for (; i < n; i++) res += el(i);
     return res;
 }
-template <int KIND>
-ORIP_HD inline float pairwise_seglen_sum(const int32_t* xy, int64_t npts) {
+template <int KIND, class PT>
+ORIP_HD inline float pairwise_seglen_sum_p(const PT& pt, int64_t npts) {
     int64_t n = npts - 1;
     if (n <= 0) return 0.f;
-    if (n <= 128) return pairwise_leaf<KIND>(xy, 0, n);
+    if (n <= 128) return pairwise_leaf_p<KIND>(pt, 0, n);
     // explicit-stack evaluation of  pw(s,n) = n<=128 ? leaf : pw(s,n2) + pw(s+n2,n-n2),  n2 = n/2 - (n/2)%8
     int64_t fs[48], fn[48]; int fstate[48]; float fleft[48];
     int sp = 0; fs[0] = 0; fn[0] = n; fstate[0] = 0; sp = 1;
     float ret = 0.f;
     while (sp > 0) {
         int t = sp - 1;
-        if (fn[t] <= 128) { ret = pairwise_leaf<KIND>(xy, fs[t], fn[t]); sp--; continue; }
+        if (fn[t] <= 128) { ret = pairwise_leaf_p<KIND>(pt, fs[t], fn[t]); sp--; continue; }
         int64_t n2 = fn[t] / 2; n2 -= n2 % 8;
         if (fstate[t] == 0) { fstate[t] = 1; fs[sp] = fs[t]; fn[sp] = n2; fstate[sp] = 0; sp++; }
         else if (fstate[t] == 1) { fleft[t] = ret; fstate[t] = 2; fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fstate[sp] = 0; sp++; }
@@ -56,15 +64,20 @@ ORIP_HD inline float pairwise_seglen_sum(const int32_t* xy, int64_t npts) {
     }
     return ret;
 }
+template <int KIND> ORIP_HD inline float pairwise_leaf(const int32_t* xy, int64_t s, int64_t n) { return pairwise_leaf_p<KIND>(XYPtr{xy}, s, n); }
+template <int KIND> ORIP_HD inline float pairwise_seglen_sum(const int32_t* xy, int64_t npts) { return pairwise_seglen_sum_p<KIND>(XYPtr{xy}, npts); }
 
 // cv::arcLength on int points (07:50 closed, 10:43 open): float per-edge sqrt accumulated in double
-ORIP_HD inline double arc_length(const int32_t* xy, int64_t n, bool closed) {
+template <class PT>
+ORIP_HD inline double arc_length_p(const PT& pt, int64_t n, bool closed) {
     if (n <= 1) return 0.0;
     int64_t last = closed ? n - 1 : 0;
-    float pvx = (float)xy[2 * last], pvy = (float)xy[2 * last + 1];
+    const IPt pl = pt(last);
+    float pvx = (float)pl.x, pvy = (float)pl.y;
     double per = 0;
     for (int64_t i = 0; i < n; i++) {
-        float x = (float)xy[2 * i], y = (float)xy[2 * i + 1];
+        const IPt q = pt(i);
+        float x = (float)q.x, y = (float)q.y;
         float dx = x - pvx, dy = y - pvy;
         float qx = dx * dx, qy = dy * dy;
         per += (double)sqrtf(qx + qy);
@@ -72,6 +85,7 @@ ORIP_HD inline double arc_length(const int32_t* xy, int64_t n, bool closed) {
     }
     return per;
 }
+ORIP_HD inline double arc_length(const int32_t* xy, int64_t n, bool closed) { return arc_length_p(XYPtr{xy}, n, closed); }
 
 // ---- cv::minEnclosingCircle on int points converted to float (08:212, 10:46,113); recalled from OpenCV 4.x ----
 struct P2 { float x, y; };

@@ -13,12 +13,39 @@ __global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, 
     }
 }
 
-extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
-    orip_enter(c);
+// explicit points of a walk-coded list, on request (orip_get_polys, consumers that read int32 pairs); enqueued on the calling lane's stream
+int orip_polys_materialize(orip_ctx* c, DPolys& P) {
+    if (!is_coded(P)) return 0;
+    VSrc src; ORIP_TRY(vsrc_of(c, P, src));
+    HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(P.total, 1) * 8 + 64));
+    if (P.n > 0 && P.total > 0) {
+        ProfScope ps(c, "k_expand_pts");
+        hipLaunchKernelGGL(k_expand_pts<VSrc>, dim3((unsigned)cdiv(P.total, 4096)), dim3(256), 0, LN(c).stream, src, P.n, reinterpret_cast<int2*>(P.pts.p), P.total);
+    }
+    HIPC(c, hipGetLastError());
+    P.pts_ok = true;
+    return 0;
+}
+
+// `sync`: the public entry points return with the lane's stream drained (the caller may read the slot from another lane next);
+// orip_layer_front chains the stages of a layer on one stream and skips the waits in between
+int orip_scale_vectors_impl(orip_ctx* c, int layer, float sx, float sy, float dx, float dy, bool sync) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     ORIP_LANE(c, layer + 1);
     DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
     D.n = S.n; D.total = S.total;
+    if (is_coded(S) && !S.scaled) {
+        // walk-coded contours: the scaled list is the same walks with _scale_one applied wherever a point is generated (vsrc.h) -- no pass over the points
+        D.virt = true; D.pts_ok = false; D.vident = S.vident; D.vlayer = S.vlayer; D.vepoch = S.vepoch;
+        D.scaled = true; D.sx = sx; D.sy = sy; D.dx = dx; D.dy = dy;
+        HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
+        HIPC(c, hipMemcpyAsync(D.off.p, S.off.p, (size_t)(S.n + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
+        if (!S.vident) { HIPC(c, D.vview.ensure((size_t)std::max<int64_t>(S.n, 1) * sizeof(VView) + 64)); HIPC(c, hipMemcpyAsync(D.vview.p, S.vview.p, (size_t)S.n * sizeof(VView), hipMemcpyDeviceToDevice, LN(c).stream)); }
+        if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
+        return 0;
+    }
+    ORIP_TRY(orip_polys_materialize(c, S));
+    D.set_explicit();
     HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
     HIPC(c, D.pts.ensure((size_t)std::max<int64_t>(S.total, 1) * 8 + 64));
     if (S.n == 0) { HIPC(c, hipMemsetAsync(D.off.p, 0, 8, LN(c).stream)); return 0; }
@@ -29,17 +56,24 @@ extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, fl
                            reinterpret_cast<const int2*>(S.pts.p), reinterpret_cast<int2*>(D.pts.p), S.total, sx, sy, dx, dy);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }
-
-extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
+extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, float dx, float dy) {
     orip_enter(c);
+    return orip_scale_vectors_impl(c, layer, sx, sy, dx, dy, true);
+}
+
+int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     ORIP_LANE(c, layer + 1);
     ORIP_TRY(vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7));
-    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
+}
+extern "C" int orip_sort_contours(orip_ctx* c, int layer) {
+    orip_enter(c);
+    return orip_sort_contours_impl(c, layer, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -279,7 +313,7 @@ extern "C" int orip_plot_order(orip_ctx* c, int layer, double R_insert, int64_t*
     uint8_t* alive_l = (uint8_t*)(feat + std::max<int64_t>(nl, 1)); uint8_t* alive_t = alive_l + nl;
     HIPC(c, c->ops[layer].ensure((size_t)(nl + nt) * 20 + 64));
     HIPC(c, T.xy.ensure(64));
-    if (nl) ORIP_TRY(vfeatures(c, L.off.as<int64_t>(), L.pts.as<int32_t>(), nl, L.total, 2, feat));
+    if (nl) ORIP_TRY(vfeatures(c, L, 2, feat));
     int* d_n = LN(c).flags.as<int>() + 40;
     const size_t lds = (size_t)nl * 17 + (size_t)nt * 9 + 64;
     if (lds <= 150 * 1024 && !getenv("ORIP_PLOT_1WG")) {

@@ -12,6 +12,7 @@
 #include "vec_common.h"
 #include <chrono>
 #include <string>
+#include <type_traits>
 #define PAD8 64
 
 int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst);
@@ -19,27 +20,35 @@ int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsig
 namespace {
 
 // ================================================================= A0 / A7: _split_small_and_taps (08:198-216)
-__global__ __launch_bounds__(128) void k_split_small08(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, orip_params08 P, const PolyFeat* __restrict__ feat,
+template <class Src>
+__global__ __launch_bounds__(128) void k_split_small08(Src src, int64_t n_polys, orip_params08 P, const PolyFeat* __restrict__ feat,
                                                         unsigned* __restrict__ is_tap, unsigned* __restrict__ is_keep, int2* __restrict__ tap_xy, GatherDesc* __restrict__ kd) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_polys) return;
     if (i == n_polys) { is_tap[i] = 0; is_keep[i] = 0; return; }
-    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
+    const int64_t n = src.len(i);
     unsigned tap = 0, keep = 0;
-    GatherDesc g; g.begin = off[i]; g.len = n; g.rev = 0; g.pad = 0;
+    GatherDesc g; g.begin = src.off[i]; g.len = n; g.rev = 0; g.src = (int32_t)i;
     if (n >= 2) {
         const int32_t x0 = feat[i].x0, x1 = feat[i].x1, y0 = feat[i].y0, y1 = feat[i].y1;      // bbox from vfeatures (long polylines: block-parallel)
         double d = (double)max(x1 - x0, y1 - y0);
         if (d <= P.tap_diam && d <= P.tap_max_dim && n <= (int64_t)P.tap_max_v) {      // the vertex test is evaluated last in the reference but decides alone
-            double per = (double)vs::pairwise_seglen_sum<0>(p, n);
-            if (per <= P.tap_max_per) {
-                float cx, cy, r; vs::min_enclosing_circle(p, n, cx, cy, r);
-                tap = 1; tap_xy[i] = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy));
+            double per; float cx, cy, r;
+            if constexpr (std::is_same<Src, ESrc>::value) {
+                const int32_t* p = reinterpret_cast<const int32_t*>(src.pts + src.off[i]);
+                per = (double)vs::pairwise_seglen_sum<0>(p, n);
+                if (per <= P.tap_max_per) vs::min_enclosing_circle(p, n, cx, cy, r);
+            } else {                                  // a tap candidate has at most tap_max_v <= 64 vertices (checked by the host): private copy
+                const auto cu = src.cur(i);
+                LocalPts<decltype(cu), 64> lp; lp.load(cu, (int)n);
+                per = (double)vs::pairwise_seglen_sum<0>(lp.xy, n);
+                if (per <= P.tap_max_per) vs::min_enclosing_circle(lp.xy, n, cx, cy, r);
             }
+            if (per <= P.tap_max_per) { tap = 1; tap_xy[i] = make_int2((int)vs::round_half_even((double)cx), (int)vs::round_half_even((double)cy)); }
         }
         if (!tap && !(d < P.min_keep)) {
             keep = 1;
-            if (p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) g.len = n - 1;      // _ensure_open
+            if (feat[i].closed) g.len = n - 1;      // _ensure_open
         }
     }
     is_tap[i] = tap; is_keep[i] = keep; kd[i] = g;
@@ -64,44 +73,46 @@ __device__ __forceinline__ void rs_finish(RsInfo& r, float acc, int64_t n, doubl
     else r.m = (unsigned)ceil(r.total / step);
     if (r.m < 2) r.m = 0;                                                             // len(S) < 2 -> nothing is drawn or stamped (08:130)
 }
-__global__ __launch_bounds__(128) void k_cumlen(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
-                                                 float* __restrict__ cum, RsInfo* __restrict__ info) {
+template <class Src>
+__global__ __launch_bounds__(128) void k_cumlen(Src src, int64_t n_polys, double step, float* __restrict__ cum, RsInfo* __restrict__ info) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_polys) return;
-    const int32_t* p = pts + 2 * off[i]; int64_t n = off[i + 1] - off[i];
-    float* s = cum + off[i];
+    const auto cu = src.cur(i); int64_t n = src.len(i);
+    float* s = cum + src.off[i];
     RsInfo r; r.n_eff = n; r.total = 0; r.m = 0; r.pass = 0;
-    if (n >= 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;         // _ensure_open inside _virtual_draw (08:127)
+    const int2 pf = cu.at(0);
+    auto same_as_first = [&](int64_t k) { const int2 q = cu.at(k); return q.x == pf.x && q.y == pf.y; };
+    if (n >= 2 && same_as_first(n - 1)) n -= 1;         // _ensure_open inside _virtual_draw (08:127)
     r.n_eff = n;
     if (n >= 2) {
-        if (n > 2 && p[0] == p[2 * (n - 1)] && p[1] == p[2 * (n - 1) + 1]) n -= 1;    // _is_closed inside _resample_arclen (08:56)
+        if (n > 2 && same_as_first(n - 1)) n -= 1;    // _is_closed inside _resample_arclen (08:56)
         r.n_eff = n;
         if (n <= ORIP_LONG_CUM) {
+            const CurPt<decltype(cu)> pt{cu};
             float acc = 0.f; s[0] = 0.f;
-            for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32(p, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
+            for (int64_t k = 0; k + 1 < n; k++) { float sl = vs::seg_len_f32_p(pt, k); acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; }
             rs_finish(r, acc, n, step);
         }
     }
     info[i] = r;
 }
-__global__ __launch_bounds__(64) void k_cumlen_long(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, int64_t n_polys, double step,
-                                                     float* __restrict__ cum, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
+template <class Src>
+__global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, double step, float* __restrict__ cum, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
     const int lane = threadIdx.x;
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = ord[rr];                 // longest perimeter first: the long chains start at once, the short ones fill in behind
         RsInfo r = info[i];
         const int64_t n = r.n_eff;
         if (n <= ORIP_LONG_CUM) continue;
-        const int32_t* p = pts + 2 * off[i]; float* s = cum + off[i];
+        const auto cu = src.cur(i); float* s = cum + src.off[i];
         const int64_t nseg = n - 1;
         float acc = 0.f;
         if (lane == 0) s[0] = 0.f;
         // four windows of 64 segment lengths per turn.  The POINTS of the next turn are requested before the serial chain of this one
         // runs and are only turned into lengths after it (using them earlier would make the chain wait for the loads after all).
-        const int2* P2 = reinterpret_cast<const int2*>(p);
         auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4]) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; const bool in = k < nseg; a[w] = in ? P2[k] : make_int2(0, 0); b2[w] = in ? P2[k + 1] : make_int2(0, 0); }
+            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; const bool in = k < nseg; a[w] = in ? cu.at(k) : make_int2(0, 0); b2[w] = in ? cu.at(k + 1) : make_int2(0, 0); }
         };
         auto lengths = [&](const int2 (&a)[4], const int2 (&b2)[4], float (&sl)[4]) {
 #pragma unroll
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(256) void k_sample_hints(const int64_t* __restrict_
     if (!ri.pass) k = sample_seg(cum + off[i], ri.n_eff, (double)sample_t(g - sbase[r], step), -1, ri.n_eff - 2);
     hints[b] = make_int2((int)r, (int)k);
 }
-__global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off, const int32_t* __restrict__ pts, const float* __restrict__ cum,
+template <class Src>
+__global__ __launch_bounds__(256) void k_samples(Src src, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
                                                   const int2* __restrict__ hints) {
@@ -184,10 +196,10 @@ __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off
     const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
     int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
     unsigned i = ord[r]; unsigned j = g - sbase[r];
-    const int32_t* p = pts + 2 * off[i]; const float* s = cum + off[i];
+    const auto cu = src.cur(i); const float* s = cum + src.off[i];
     RsInfo ri = info[i];
     double x, y;
-    if (ri.pass) { x = (double)(float)p[2 * j]; y = (double)(float)p[2 * j + 1]; }
+    if (ri.pass) { const int2 q = cu.at(j); x = (double)(float)q.x; y = (double)(float)q.y; }
     else {
         double t = (double)sample_t(j, step);
         const int64_t klo = (r == h0.x) ? h0.y : -1, khi = (!last && r == h1.x) ? h1.y : ri.n_eff - 2;
@@ -195,8 +207,9 @@ __global__ __launch_bounds__(256) void k_samples(const int64_t* __restrict__ off
         double sk = (double)s[k], sk1 = (double)s[k + 1];
         double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
         double a = __dsub_rn(1.0, u);
-        x = __dadd_rn(__dmul_rn((double)(float)p[2 * k], a), __dmul_rn((double)(float)p[2 * k + 2], u));
-        y = __dadd_rn(__dmul_rn((double)(float)p[2 * k + 1], a), __dmul_rn((double)(float)p[2 * k + 3], u));
+        const int2 p0 = cu.at(k), p1 = cu.at(k + 1);
+        x = __dadd_rn(__dmul_rn((double)(float)p0.x, a), __dmul_rn((double)(float)p1.x, u));
+        y = __dadd_rn(__dmul_rn((double)(float)p0.y, a), __dmul_rn((double)(float)p1.y, u));
     }
     long long xi = vs::round_half_even(x), yi = vs::round_half_even(y);
     A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
@@ -1003,7 +1016,7 @@ __global__ __launch_bounds__(64) void k_comp_paths_glb(CompArgs A, const unsigne
 __global__ __launch_bounds__(256) void k_path_desc(const unsigned* __restrict__ corder, const unsigned* __restrict__ cs, const unsigned* __restrict__ outcnt, const unsigned* __restrict__ flag,
                                                     const unsigned* __restrict__ scan, unsigned nc, GatherDesc* __restrict__ d) {
     unsigned oi = blockIdx.x * 256 + threadIdx.x; if (oi >= nc || !flag[oi]) return;
-    GatherDesc g; g.begin = cs[corder[oi]]; g.len = outcnt[oi]; g.rev = 0; g.pad = 0;
+    GatherDesc g; g.begin = cs[corder[oi]]; g.len = outcnt[oi]; g.rev = 0; g.src = 0;
     d[scan[oi]] = g;
 }
 __global__ __launch_bounds__(256) void k_flag_nonzero(const unsigned* __restrict__ v, unsigned n, unsigned* __restrict__ f) {
@@ -1022,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_compact_feat(const unsigned* __restrict
 // kept_feat (optional, room for src.n entries): features of the kept polylines' open views (bbox + numpy perimeter), so the caller
 // does not have to read the points again
 int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, DBuf& tapbuf, int64_t tap_base, int64_t* n_taps_out, PolyFeat* kept_feat = nullptr) {
-    kept.n = 0; kept.total = 0; *n_taps_out = 0;
+    kept.n = 0; kept.total = 0; kept.set_explicit(); *n_taps_out = 0;
     HIPC(c, kept.off.ensure(64)); HIPC(c, hipMemsetAsync(kept.off.p, 0, 8, LN(c).stream));
     int64_t n = src.n;
     if (n == 0) return 0;
@@ -1031,8 +1044,9 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     int2* tap_xy = (int2*)(keep_scan + (n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (n + 1)); GatherDesc* kd2 = kd + (n + 1);
     HIPC(c, LN(c).vtmp[10].ensure((size_t)n * sizeof(PolyFeat) + 64));
     PolyFeat* sfeat = LN(c).vtmp[10].as<PolyFeat>();
-    ORIP_TRY(vfeatures(c, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, src.total, kept_feat ? (1 | 16) : 0, sfeat));
-    { ProfScope ps(c, "k_split_small08"); hipLaunchKernelGGL(k_split_small08, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, src.off.as<int64_t>(), src.pts.as<int32_t>(), n, P, sfeat, is_tap, is_keep, tap_xy, kd); }
+    if (is_coded(src) && P.tap_max_v > 64) ORIP_TRY(orip_polys_materialize(c, src));      // the walk-coded tap test copies <= 64 vertices (default tap_max_vertices: 50)
+    ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat));
+    { ProfScope ps(c, "k_split_small08"); ORIP_WITH_SRC(c, src, sv, { hipLaunchKernelGGL(k_split_small08<decltype(sv)>, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, sv, n, P, sfeat, is_tap, is_keep, tap_xy, kd); }); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
     unsigned nt = 0, nk = 0;
@@ -1044,7 +1058,7 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     *n_taps_out = nt;
     if (nk) {
         hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, n, kd, kd2, (const int2*)nullptr, (int2*)nullptr);
-        ORIP_TRY(vgather(c, kd2, nk, src.pts.as<int32_t>(), kept));
+        ORIP_TRY(vgather_list(c, kd2, nk, src, kept));
         if (kept_feat) hipLaunchKernelGGL(k_compact_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, n, sfeat, kept_feat);
     }
     HIPC(c, hipGetLastError());
@@ -1068,12 +1082,12 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
     if (!(P.sample_step * 2.0 < P.max_jump)) ORIP_FAIL(c, "dedup_sample_step must be < max_join_jump_px / 2 (stage-A segments are assumed jump-free)");
     DPolys& S = c->polys[ORIP_SLOT_SORTED][layer]; DPolys& OUT = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DTaps& TOUT = c->taps[ORIP_TAPS_INTRA][layer];
-    OUT.n = 0; OUT.total = 0; TOUT.n = 0;
+    OUT.n = 0; OUT.total = 0; OUT.set_explicit(); TOUT.n = 0;
     HIPC(c, OUT.off.ensure(64)); HIPC(c, hipMemsetAsync(OUT.off.p, 0, 8, LN(c).stream));
     HIPC(c, TOUT.xy.ensure(64));
     if (S.n == 0) return 0;
     struct Ref { DPolys& p; }; Ref kept0{LN(c).tp[0]}, cleaned{LN(c).tp[1]}, lines2{LN(c).tp[2]}, merged{LN(c).tp[3]};
-    for (Ref* r : {&kept0, &cleaned, &lines2, &merged}) { r->p.n = 0; r->p.total = 0; }
+    for (Ref* r : {&kept0, &cleaned, &lines2, &merged}) { r->p.n = 0; r->p.total = 0; r->p.set_explicit(); }
     int64_t nt0 = 0, nt2 = 0;
     const bool tdbg = getenv("ORIP_TIME08") != nullptr;      // debug: per-phase wall times of this layer (adds stream syncs)
     std::string tlog; auto tprev = std::chrono::steady_clock::now();
@@ -1103,8 +1117,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         HIPC(c, LN(c).vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
         float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
-        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info); }
-        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), nk, step, cum, info, ord); }
+        { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
+        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen_long<decltype(sv)>, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
         tick("cumlen");
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
@@ -1122,7 +1136,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
             int2* hints = (int2*)(LN(c).vtmp[5].as<uint8_t>() + (((size_t)MS * 24 + 63) & ~(size_t)63));
             hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), cum, info, ord, sbase, nk, MS, step, nb, hints);
-            { ProfScope ps(c, "k_samples"); hipLaunchKernelGGL(k_samples, dim3(nb), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), kept0.p.pts.as<int32_t>(), cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin, hints); }
+            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin, hints); }); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
@@ -1218,7 +1232,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         HIPC(c, LN(c).vtmp[6].ensure((size_t)n2 * sizeof(PolyFeat) + (size_t)(n2 + 1) * (4 + 4 + 4) + (size_t)n2 * sizeof(GroupInfo) + 256));
         PolyFeat* f2 = LN(c).vtmp[6].as<PolyFeat>(); int* par = (int*)(f2 + n2); unsigned* is_root = (unsigned*)(par + (n2 + 1)); unsigned* root_scan = is_root + (n2 + 1);
         GroupInfo* grp = (GroupInfo*)(root_scan + (n2 + 1) + ((3 * (n2 + 1)) & 1));
-        ORIP_TRY(vfeatures(c, lines2.p.off.as<int64_t>(), lines2.p.pts.as<int32_t>(), n2, lines2.p.total, 1, f2));
+        ORIP_TRY(vfeatures(c, lines2.p, 1, f2));
         hipLaunchKernelGGL(k_iota, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, par, (int)n2);
         { ProfScope ps(c, "k_bbox_pairs"); hipLaunchKernelGGL(k_bbox_pairs, dim3((unsigned)std::min<int64_t>(n2, 8192)), dim3(256), 0, LN(c).stream, f2, (int)n2, exp, par); }
         hipLaunchKernelGGL(k_group_init, dim3(cdiv(n2, 256)), dim3(256), 0, LN(c).stream, grp, (int)n2);
@@ -1361,14 +1375,14 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 hipLaunchKernelGGL(k_flag_nonzero, dim3(cdiv(NC + 1, 256)), blk, 0, LN(c).stream, outcnt, NC, oflag);
                 ORIP_TRY(vscan_excl<unsigned>(c, oflag, oscan, (size_t)NC + 1));
                 unsigned NP = 0; ORIP_TRY(vread(c, &NP, oscan + NC));
-                merged.p.n = 0; merged.p.total = 0;
+                merged.p.n = 0; merged.p.total = 0; merged.p.set_explicit();
                 HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream));
                 if (NP) {
                     hipLaunchKernelGGL(k_path_desc, dim3(cdiv(NC, 256)), blk, 0, LN(c).stream, corder, cs, outcnt, oflag, oscan, NC, pd);
                     ORIP_TRY(vgather(c, pd, NP, reinterpret_cast<const int32_t*>(outpts), merged.p));
                 }
             }
-        } else { merged.p.n = 0; merged.p.total = 0; HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream)); }
+        } else { merged.p.n = 0; merged.p.total = 0; merged.p.set_explicit(); HIPC(c, merged.p.off.ensure(64)); HIPC(c, hipMemsetAsync(merged.p.off.p, 0, 8, LN(c).stream)); }
         HIPC(c, hipGetLastError());
         fin = &merged.p;
     }
@@ -1387,9 +1401,9 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
 extern "C" int orip_layer_front(orip_ctx* c, int layer, float sx, float sy, float dx, float dy, int upto, const orip_params08* prm) {
     orip_enter(c);
     if (upto >= 8 && !prm) ORIP_FAIL(c, "stage 08 needs its parameters");
-    ORIP_TRY(orip_contours_layer(c, layer));
-    ORIP_TRY(orip_scale_vectors(c, layer, sx, sy, dx, dy));
-    if (upto >= 7) ORIP_TRY(orip_sort_contours(c, layer));
+    ORIP_TRY(orip_contours_layer_impl(c, layer, false));
+    ORIP_TRY(orip_scale_vectors_impl(c, layer, sx, sy, dx, dy, upto < 7));
+    if (upto >= 7) ORIP_TRY(orip_sort_contours_impl(c, layer, upto < 8));
     if (upto >= 8) ORIP_TRY(orip_dedup_layer(c, layer, prm));
     return 0;
 }

@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void k_run_desc(const unsigned* __restrict__ r
                                                    const unsigned* __restrict__ keep_scan, unsigned n_runs, GatherDesc* __restrict__ d) {
     unsigned r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_runs || !keep[r]) return;
-    GatherDesc g; g.begin = rbegin[r]; g.len = rlen[r]; g.rev = 0; g.pad = 0;
+    GatherDesc g; g.begin = rbegin[r]; g.len = rlen[r]; g.rev = 0; g.src = 0;
     d[keep_scan[r]] = g;
 }
 
 // Shared by stage 08-A and stage 10: turn per-slot flags (bit0 accepted, bit1 sequence start) + points into a DPolys of runs with >= 2 points
 int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsigned n_slots, DPolys& dst) {
-    dst.n = 0; dst.total = 0;
+    dst.n = 0; dst.total = 0; dst.set_explicit();
     HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream));
     if (n_slots == 0) return 0;
     HIPC(c, LN(c).vtmp[7].ensure((size_t)n_slots * 8 + 64));
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_compact_sel(const unsigned* __restrict_
                                                       GatherDesc* __restrict__ d, const int2* __restrict__ tap_xy, int2* __restrict__ taps_out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !flag[i]) return;
-    if (d) { GatherDesc g; g.begin = off[i]; g.len = off[i + 1] - off[i]; g.rev = 0; g.pad = 0; d[scan[i]] = g; }
+    if (d) { GatherDesc g; g.begin = off[i]; g.len = off[i + 1] - off[i]; g.rev = 0; g.src = (int32_t)i; d[scan[i]] = g; }
     if (taps_out) taps_out[scan[i]] = tap_xy[i];
 }
 
@@ -447,7 +447,8 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         DTaps& Tin = c->taps[ORIP_TAPS_INTRA][src_layer]; DTaps& Tout = c->taps[ORIP_TAPS_CROSS][layer];
         // ---- 1) cut
         DPolys& cut = LN(c).tp[4]; DPolys& keepl = LN(c).tp[5];   // persistent temporaries of this lane
-        cut.n = 0; cut.total = 0;
+        cut.n = 0; cut.total = 0; cut.set_explicit();
+        ORIP_TRY(orip_polys_materialize(c, Lin));      // stage 08 leaves explicit lists; a walk-coded one set up by hand is expanded first
         if (Lin.n > 0 && Lin.total > 0) {
             if (Lin.total > 0x7fffffff) ORIP_FAIL(c, "layer too large");
             HIPC(c, LN(c).vtmp[0].ensure((size_t)(Lin.total + 1) * 9 + 64));
@@ -467,7 +468,7 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         auto t1 = tdbg ? now() : t0;
         // ---- 2,3) jumps are the identity; tiny lines -> taps / dropped
         int64_t n_tap_lines = 0;
-        keepl.n = 0; keepl.total = 0;
+        keepl.n = 0; keepl.total = 0; keepl.set_explicit();
         HIPC(c, LN(c).vtmp[2].ensure((size_t)(cut.n + 1) * (16 + 8 + sizeof(GatherDesc)) + 256));
         unsigned* is_tap = LN(c).vtmp[2].as<unsigned>(); unsigned* is_keep = is_tap + (cut.n + 1); unsigned* tap_scan = is_keep + (cut.n + 1); unsigned* keep_scan = tap_scan + (cut.n + 1);
         int2* tap_xy = (int2*)(keep_scan + (cut.n + 1)); GatherDesc* kd = (GatherDesc*)(tap_xy + (cut.n + 1));
@@ -475,7 +476,7 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         if (cut.n > 0) {
             HIPC(c, LN(c).vtmp[10].ensure((size_t)cut.n * sizeof(PolyFeat) + 64));
             PolyFeat* cfeat = LN(c).vtmp[10].as<PolyFeat>();
-            ORIP_TRY(vfeatures(c, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, cut.total, 0, cfeat));
+            ORIP_TRY(vfeatures(c, cut, 0, cfeat));
             hipLaunchKernelGGL(k_tiny_taps10, dim3((unsigned)std::min<int64_t>(cut.n + 1, 65535)), dim3(64), 0, LN(c).stream, cut.off.as<int64_t>(), cut.pts.as<int32_t>(), cut.n, P, cfeat, is_tap, is_keep, tap_xy);
             ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
             ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));

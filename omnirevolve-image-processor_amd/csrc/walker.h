@@ -825,3 +825,75 @@ ORIP_HD inline void write_chunk(const WalkArgs& A, int layer, const unsigned* ke
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Walk-coded contours.  A kept walk is: its start pixel, n_own steps (explicit points, a few per skeleton pixel) and, for a
+// leftover walk that ran into a recorded trajectory, R tail points that are a chain of log-record pieces ending in a cycle that is
+// repeated until the guard (04:199) fires -- up to 4 * fg points for a handful of distinct ones.  Stage 04 leaves these records;
+// the point lists of 04 / 05 / 07 and the front of 08 are VIEWS over them (vsrc.h), and write_chunk above is only the reference
+// expansion (tests/host).  tail point u (0 <= u < R) of a walk = pixel of log entry E(u); E is piecewise:
+//   piece j covers [u0_j, u0_{j+1}):  E(u) = ent_j + (u - u0_j)           (lam_j == 0, the rest of a record)
+//                                     E(u) = ent_j + (u - u0_j) % lam_j   (lam_j  > 0, the closing cycle: always the last piece)
+// ------------------------------------------------------------------------------------------------
+struct VWalk { unsigned own_off, n_own, piece_off, n_piece, len, flags, pad0, pad1; };     // flags bit0: the last point is the start again (04:203-204)
+struct VPiece { unsigned u0, ent, lam, pad; };                                            // ent: index into the layer's log buffer
+struct VView { unsigned wid, first, len, rev; };                                          // polyline = points first .. first+len-1 of walk wid, reversed if rev
+
+// pieces of the tail of a kept walk; emit(j, u0, entry, lam) with GLOBAL entry indices (as the trace addressed the log).  Returns their number.
+template <class WaveT, class Emit>
+ORIP_HD inline unsigned vwalk_pieces(const unsigned* logbuf, const WaveT& wv, const WalkInfo& wi, Emit&& emit) {
+    if (!wi.log_i1) return 0u;
+    unsigned n = 0; unsigned long long done = 0, f0 = wi.log_i1; unsigned rec = wi.log_i1 - 1;
+    while (done < wi.R) {
+        unsigned cont, en, begin; wv.ld0_rec(&logbuf[4ull * rec], cont, en, begin);
+        if (f0 < en) { emit(n++, (unsigned)done, (unsigned)f0, 0u); done += en - f0; if (done >= wi.R) break; }      // the rest of this record
+        if (cont >= begin) { emit(n++, (unsigned)done, cont, en - cont); break; }                                    // cycle [cont, en): everything that is left
+        f0 = cont; rec = cont;                                                                                       // transient record exhausted: on into the older record
+    }
+    return n;
+}
+
+// Own points [q0, q1) of a layer (positions in the concatenation of the kept walks' start + own-step points: walk i holds n_own + 1 of
+// them from vw[i].own_off), written by one wavefront: prefix sums over the direction codes, as write_chunk does for a walk's own steps.
+ORIP_HD inline void own_chunk(const WalkArgs& A, const unsigned* kept, const VWalk* vw, unsigned n_kept, int2* own, unsigned q0, unsigned q1) {
+    using namespace walk_detail;
+    Wave wv;
+    const int W = A.W;
+    unsigned lo = 0, hi = n_kept;
+    while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (vw[mid].own_off <= q0) lo = mid; else hi = mid; }
+    for (unsigned i = lo; i < n_kept; i++) {
+        const VWalk w = vw[i];
+        if (w.own_off >= q1) break;
+        const unsigned L = w.n_own + 1u;
+        const unsigned ta = (q0 > w.own_off ? q0 : w.own_off) - w.own_off, tb = (q1 < w.own_off + L ? q1 : w.own_off + L) - w.own_off;     // this walk's own points [ta, tb)
+        if (ta >= tb) continue;
+        const unsigned slot = kept[i];
+        const WalkInfo wi = A.winfo[slot];
+        unsigned clo = 0, chi = A.nc;
+        while (clo < chi) { unsigned mid = (clo + chi) >> 1; if (2u * A.comp_start[mid + 1] <= slot) clo = mid + 1; else chi = mid; }
+        const unsigned b = A.comp_start[clo], fg = A.comp_start[clo + 1] - b, rel = slot - 2u * b;
+        const unsigned s = A.lin[b + (rel >= fg ? rel - fg : rel)];
+        const int x0 = (int)(s % (unsigned)W), y0 = (int)(s / (unsigned)W);
+        int2* out = own + w.own_off;
+        if (wv.leader() && ta == 0) out[0] = make_int2(x0, y0);
+        const unsigned own_a = ta > 1u ? ta : 1u, own_b = tb;
+        if (own_a < own_b) {
+            int cx = x0, cy = y0;
+            for (unsigned c0 = 0; c0 < own_a - 1u; c0 += wv.nl()) {              // codes before the chunk: only their sum
+                const unsigned t = c0 + wv.l0();
+                int dx = 0, dy = 0;
+                if (t < own_a - 1u) { const int k = A.steplog[(size_t)wi.step_begin + t]; dx = nbx(k); dy = nby(k); }
+                int ox, oy, tx, ty; wv.scan2(dx, dy, ox, oy, tx, ty);
+                cx += tx; cy += ty;
+            }
+            for (unsigned t0 = own_a; t0 < own_b; t0 += wv.nl()) {
+                const unsigned t = t0 + wv.l0();
+                int dx = 0, dy = 0;
+                if (t < own_b) { const int k = A.steplog[(size_t)wi.step_begin + t - 1]; dx = nbx(k); dy = nby(k); }
+                int ox, oy, tx, ty; wv.scan2(dx, dy, ox, oy, tx, ty);
+                if (t < own_b) out[t] = make_int2(cx + ox, cy + oy);
+                cx += tx; cy += ty;
+            }
+        }
+    }
+}
