@@ -52,7 +52,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     }
     for (int s = 0; s < ORIP_SLOT_COUNT; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) { c->polys[s][l].off.release(); c->polys[s][l].pts.release(); c->polys[s][l].vview.release(); }
     for (auto& l : c->ln) for (auto& t : l.tp) { t.off.release(); t.pts.release(); t.vview.release(); }
-    for (auto& w : c->wstore) { w.log.release(); w.walk.release(); w.piece.release(); w.own.release(); }
+    for (auto& w : c->wstore) for (DBuf* b : {&w.log, &w.walk, &w.piece, &w.own, &w.lxy, &w.ent_idx, &w.cnt, &w.own_s, &w.lxy_s}) b->release();
     for (int s = 0; s < 2; s++) for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->taps[s][l].xy.release();
     for (int l = 0; l < ORIP_MAX_LAYERS; l++) c->ops[l].release();
     orip_contours_free(c);

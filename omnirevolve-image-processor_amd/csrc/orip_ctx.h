@@ -67,16 +67,22 @@ struct DPolys {
     bool vident = true;
     int vlayer = 0;             // whose WalkStore
     uint64_t vepoch = 0;        // WalkStore::epoch the list was built on: a later trace of the layer makes it stale
-    bool scaled = false; float sx = 1.f, sy = 1.f, dx = 0.f, dy = 0.f;     // _scale_one (05:82-96) applied on the fly
+    uint64_t vsepoch = 0;       // scaled lists: WalkStore::sepoch of the scaled tables they read
+    bool scaled = false;        // reads the scaled tables of the WalkStore
     void set_explicit() { virt = false; pts_ok = true; }
 };
 // What stage 04 leaves per layer (raster04.hip: trace_finish) and every walk-coded list of the layer reads
 struct WalkStore {
     DBuf log;                   // the trace's state log (walker.h: 4 words per entry)
-    DBuf walk, piece, own;      // VWalk[n], VPiece[...], int2 own points
-    int64_t n = 0;
+    DBuf walk, piece, own;      // VWalk[n], VPiece[...], int2 own points (start + own steps of every kept walk)
+    DBuf lxy;                   // int2 pixel of every log entry in use (same index as the log)
+    DBuf ent_idx, cnt;          // the indices of those entries, in any order; cnt[0] = how many (device side: nobody on the host needs it)
+    DBuf own_s, lxy_s;          // the same two tables after _scale_one (05:82-96) with (sx, sy, dx, dy): what a scaled list reads
+    float sx = 1.f, sy = 1.f, dx = 0.f, dy = 0.f;
+    int64_t n = 0, n_own = 0, ent_cap = 0;
     int W = 0;
-    uint64_t epoch = 0;
+    uint64_t epoch = 0;         // bumped by every trace of the layer
+    uint64_t sepoch = 0;        // bumped whenever own_s / lxy_s are rewritten
 };
 struct DTaps {
     DBuf xy;  // int32[2*n]

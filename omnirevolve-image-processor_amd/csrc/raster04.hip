@@ -145,35 +145,54 @@ __global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, int layer, const
 }
 // lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here.
 // opc: own points (n_own + 1) << 32 | tail pieces of a kept walk (one scan sizes both arrays of the walk-coded form)
-__global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, unsigned long long* __restrict__ lens, unsigned* __restrict__ kept, unsigned long long* __restrict__ opc) {
+struct WSum {       // what one walk slot adds to the layer's list: one scan sizes and places everything
+    unsigned long long pts; unsigned paths, own, pieces, pad;
+    __host__ __device__ WSum operator+(const WSum& o) const { WSum r; r.pts = pts + o.pts; r.paths = paths + o.paths; r.own = own + o.own; r.pieces = pieces + o.pieces; r.pad = 0; return r; }
+};
+__global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, WSum* __restrict__ ws) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
+    WSum s; s.pts = 0; s.paths = 0; s.own = 0; s.pieces = 0; s.pad = 0;
     if (i < n) {
         WalkInfo w = A.winfo[slot0 + i];
         if (w.flags & 2u) { walk_close_tail(A, PlainReader(), slot0 + i, w); A.winfo[slot0 + i] = w; }
-        lens[i] = w.len_kept; kept[i] = w.len_kept ? 1u : 0u;
-        unsigned long long o = 0;
-        if (w.len_kept) o = ((unsigned long long)(w.n_own + 1u) << 32) | vwalk_pieces(A.logbuf, PlainReader(), w, [](unsigned, unsigned, unsigned, unsigned) {});
-        opc[i] = o;
+        if (w.len_kept) { s.pts = w.len_kept; s.paths = 1u; s.own = w.n_own + 1u; s.pieces = vwalk_pieces(A.logbuf, PlainReader(), w, [](unsigned, unsigned, unsigned, unsigned) {}); }
     }
-    if (i == n) { lens[i] = 0; kept[i] = 0; opc[i] = 0; }
+    if (i <= n) ws[i] = s;
 }
-// totals of the three scans in one row: points, paths, own points, pieces
-__global__ void k_walk_totals(const unsigned long long* __restrict__ pts_off, const unsigned* __restrict__ path_off, const unsigned long long* __restrict__ opc_off, unsigned n, unsigned long long* __restrict__ out) {
-    out[0] = pts_off[n]; out[1] = path_off[n]; out[2] = opc_off[n] >> 32; out[3] = opc_off[n] & 0xffffffffull;
+// pixel of every log entry in use, and the list of those entries (any order: blocks take their ranges with one atomic each).
+// blockIdx.x = component of the layer, blockIdx.y = slice of its entries
+__global__ __launch_bounds__(256) void k_ent_fill(WalkArgs A, unsigned c0, unsigned log_shift, int2* __restrict__ lxy, unsigned* __restrict__ ent_idx, unsigned* __restrict__ cnt, unsigned cap) {
+    __shared__ unsigned base_s;
+    const unsigned c = c0 + blockIdx.x;
+    const unsigned used = A.log_used[c];
+    const unsigned per = (used + gridDim.y - 1) / gridDim.y, t0 = blockIdx.y * per, t1 = min(used, t0 + per);
+    if (t0 >= t1) return;
+    if (threadIdx.x == 0) base_s = atomicAdd(cnt, t1 - t0);
+    __syncthreads();
+    const unsigned base = base_s;
+    const unsigned lb = A.cap_factor * A.comp_start[c] + 64u * c;           // first entry of the component (walker.h: trace_component)
+    const unsigned W = (unsigned)A.W;
+    for (unsigned t = t0 + threadIdx.x; t < t1; t += 256) {
+        const unsigned e = lb + t, lin = A.logbuf[4ull * e] >> 3;
+        const unsigned y = lin / W;
+        lxy[e - log_shift] = make_int2((int)(lin - y * W), (int)y);
+        if (base + (t - t0) < cap) ent_idx[base + (t - t0)] = e - log_shift;
+    }
 }
 // the walk-coded form of the layer's contours: one VWalk per kept walk (path order = slot order), its tail pieces, its offset in the list
-__global__ __launch_bounds__(256) void k_vwalk_fill(WalkArgs A, unsigned slot0, unsigned n, const unsigned* __restrict__ kept, const unsigned* __restrict__ path_off,
-                                                     const unsigned long long* __restrict__ pts_off, const unsigned long long* __restrict__ opc_off, unsigned log_shift,
+__global__ __launch_bounds__(256) void k_vwalk_fill(WalkArgs A, unsigned slot0, unsigned n, const WSum* __restrict__ wo /* exclusive scan */, unsigned log_shift,
                                                      VWalk* __restrict__ vw, VPiece* __restrict__ vp, unsigned* __restrict__ kept_slots, int64_t* __restrict__ off) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i == n) off[path_off[n]] = (int64_t)pts_off[n];
-    if (i >= n || !kept[i]) return;
+    if (i == n) off[wo[n].paths] = (int64_t)wo[n].pts;
+    if (i >= n) return;
+    const WSum o = wo[i];
+    if (wo[i + 1].paths == o.paths) return;            // not kept
     const WalkInfo w = A.winfo[slot0 + i];
-    VWalk v; v.own_off = (unsigned)(opc_off[i] >> 32); v.n_own = w.n_own; v.piece_off = (unsigned)(opc_off[i] & 0xffffffffull); v.len = w.len_kept; v.flags = w.flags & 1u; v.pad0 = v.pad1 = 0;
+    VWalk v; v.own_off = o.own; v.n_own = w.n_own; v.piece_off = o.pieces; v.len = w.len_kept; v.flags = w.flags & 1u; v.pad0 = v.pad1 = 0;
     VPiece* mine = vp + v.piece_off;
-    v.n_piece = vwalk_pieces(A.logbuf, PlainReader(), w, [&](unsigned j, unsigned u0, unsigned ent, unsigned lam) { VPiece q; q.u0 = u0; q.ent = ent - log_shift; q.lam = lam; q.pad = 0; mine[j] = q; });
-    const unsigned pi = path_off[i];
-    vw[pi] = v; kept_slots[pi] = slot0 + i; off[pi] = (int64_t)pts_off[i];
+    v.n_piece = vwalk_pieces(A.logbuf, PlainReader(), w, [&](unsigned j, unsigned u0, unsigned ent, unsigned lam) { VPiece q; q.u0 = u0; q.ent = ent - log_shift; q.lam = lam; q.magic = lam > 1u ? (unsigned)(0x100000000ull / lam) : 0xffffffffu; mine[j] = q; });
+    const unsigned pi = o.paths;
+    vw[pi] = v; kept_slots[pi] = slot0 + i; off[pi] = (int64_t)o.pts;
 }
 // own points of the kept walks, one wavefront per chunk
 __global__ __launch_bounds__(64) void k_vown(WalkArgs A, const unsigned* __restrict__ kept_slots, const VWalk* __restrict__ vw, unsigned n_kept, int2* __restrict__ own, unsigned total, unsigned chunk) {
@@ -475,6 +494,8 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     HIPC(c, LN(c).vtmp[6].ensure(plane * (size_t)K * 8 * 4 + 64));
     HIPC(c, LN(c).vtmp[8].ensure((size_t)2 * M * sizeof(WalkInfo) + 64));
     A.memo = LN(c).vtmp[6].as<unsigned>(); A.winfo = LN(c).vtmp[8].as<WalkInfo>();
+    HIPC(c, LN(c).vtmp[7].ensure((size_t)(NC + 1) * 4 + 64));
+    A.log_used = LN(c).vtmp[7].as<unsigned>();         // written by every component's trace
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     R.ready = true;
     return 0;
@@ -546,26 +567,35 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
     const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
     const size_t ns1 = (size_t)nslots + 1;
-    HIPC(c, LN(c).vtmp[4].ensure(ns1 * (8 + 8 + 8 + 8 + 4 + 4) + 256));
-    unsigned long long* lens = LN(c).vtmp[4].as<unsigned long long>(); unsigned long long* pts_off = lens + ns1; unsigned long long* opc = pts_off + ns1; unsigned long long* opc_off = opc + ns1;
-    unsigned* kept = (unsigned*)(opc_off + ns1); unsigned* path_off = kept + ns1;
+    HIPC(c, LN(c).vtmp[4].ensure(ns1 * 2 * sizeof(WSum) + 256));
+    WSum* ws = LN(c).vtmp[4].as<WSum>(); WSum* wo = ws + ns1;
     WalkStore& WS = c->wstore[layer];
     const unsigned log_shift = (unsigned)((size_t)R.F[layer] * b0 + (size_t)64 * c0);
     WalkArgs A = R.A;                        // the layer's logs as the trace addressed them (walk_close_tail / vwalk_pieces follow the recorded trajectories)
     A.logbuf = WS.log.as<unsigned>() - 4 * (size_t)log_shift;
     A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
     A.cap_factor = R.F[layer];
-    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, lens, kept, opc);
-    ORIP_TRY(excl_scan<unsigned long long>(c, lens, pts_off, ns1, LN(c).tmpF));
-    ORIP_TRY(excl_scan<unsigned>(c, kept, path_off, ns1, LN(c).tmpF));
-    ORIP_TRY(excl_scan<unsigned long long>(c, opc, opc_off, ns1, LN(c).tmpF));
-    unsigned long long* d_tot = LN(c).flags.as<unsigned long long>() + 120;       // bytes 960..992 of the lane's flag page
-    hipLaunchKernelGGL(k_walk_totals, dim3(1), dim3(1), 0, LN(c).stream, pts_off, path_off, opc_off, nslots, d_tot);
-    unsigned long long h_tot[4] = {0, 0, 0, 0};
-    HIPC(c, hipMemcpyAsync(h_tot, d_tot, 32, hipMemcpyDeviceToHost, LN(c).stream));
+    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, ws);
+    {
+        size_t bytes = 0; WSum zero; zero.pts = 0; zero.paths = zero.own = zero.pieces = zero.pad = 0;
+        HIPC(c, rocprim::exclusive_scan(nullptr, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
+        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+        HIPC(c, rocprim::exclusive_scan(LN(c).tmpF.p, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
+    }
+    WSum h_tot;
+    HIPC(c, hipMemcpyAsync(&h_tot, wo + nslots, sizeof(WSum), hipMemcpyDeviceToHost, LN(c).stream));
+    // pixels of the log entries in use (needs nothing from the scan: it runs while the host waits for the totals)
+    {
+        const unsigned NCl = c1 - c0;
+        WS.ent_cap = (int64_t)8 * Ml + 64;                       // a component logs at most one entry per (pixel, incoming direction)
+        HIPC(c, WS.lxy.ensure(((size_t)R.F[layer] * Ml + (size_t)64 * NCl + 8) * 8 + 64));
+        HIPC(c, WS.ent_idx.ensure((size_t)WS.ent_cap * 4 + 64));
+        HIPC(c, WS.cnt.ensure(64));
+        HIPC(c, hipMemsetAsync(WS.cnt.p, 0, 4, LN(c).stream));
+        hipLaunchKernelGGL(k_ent_fill, dim3(NCl, 8), block, 0, LN(c).stream, A, c0, log_shift, WS.lxy.as<int2>(), WS.ent_idx.as<unsigned>(), WS.cnt.as<unsigned>(), (unsigned)WS.ent_cap);
+    }
     HIPC(c, hipStreamSynchronize(LN(c).stream));
-    const unsigned long long h_pts = h_tot[0]; const unsigned h_paths = (unsigned)h_tot[1], h_own = (unsigned)h_tot[2], h_pieces = (unsigned)h_tot[3];
-    if (h_tot[2] > 0xfffffff0ull) ORIP_FAIL(c, "layer %d: too many own points for the walk-coded form", layer);
+    const unsigned long long h_pts = h_tot.pts; const unsigned h_paths = h_tot.paths, h_own = h_tot.own, h_pieces = h_tot.pieces;
     // ---- the contours of the layer in walk-coded form (walker.h): nothing is expanded here
     DPolys& P = c->polys[ORIP_SLOT_CONTOURS][layer];
     P.total = (int64_t)h_pts; P.n = (int64_t)h_paths;
@@ -576,8 +606,8 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     HIPC(c, WS.own.ensure((size_t)std::max(h_own, 1u) * 8 + 64));
     HIPC(c, LN(c).vtmp[5].ensure((size_t)std::max(h_paths, 1u) * 4 + 64));
     unsigned* kept_slots = LN(c).vtmp[5].as<unsigned>();
-    WS.n = P.n; WS.W = R.A.W;
-    hipLaunchKernelGGL(k_vwalk_fill, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, kept, path_off, pts_off, opc_off, log_shift,
+    WS.n = P.n; WS.W = R.A.W; WS.n_own = h_own;
+    hipLaunchKernelGGL(k_vwalk_fill, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, wo, log_shift,
                        WS.walk.as<VWalk>(), WS.piece.as<VPiece>(), kept_slots, P.off.as<int64_t>());
     if (h_paths) {
         ProfScope ps(c, "k_write_walks");

@@ -53,9 +53,9 @@ static int vsrc_of(orip_ctx* c, const DPolys& P, VSrc& out) {
     const WalkStore& WS = c->wstore[P.vlayer];
     if (P.vepoch != WS.epoch) ORIP_FAIL(c, "the walk records of layer %d this list was built on have been replaced by a newer orip_contours_layer", P.vlayer);
     out.off = P.off.as<int64_t>(); out.view = P.vident ? nullptr : P.vview.as<VView>(); out.walk = WS.walk.as<VWalk>();
-    out.g.piece = WS.piece.as<VPiece>(); out.g.own = WS.own.as<int2>(); out.g.logw = WS.log.as<unsigned>();
-    out.g.W = (unsigned)WS.W; out.g.wmagic = ((1ull << 40) + (unsigned long long)WS.W - 1ull) / (unsigned long long)WS.W;
-    out.g.scaled = P.scaled ? 1 : 0; out.g.sx = P.sx; out.g.sy = P.sy; out.g.dx = P.dx; out.g.dy = P.dy;
+    if (P.scaled && P.vsepoch != WS.sepoch) ORIP_FAIL(c, "the scaled walk records of layer %d this list was built on have been replaced by a newer orip_scale_vectors", P.vlayer);
+    out.g.piece = WS.piece.as<VPiece>();
+    out.g.own = P.scaled ? WS.own_s.as<int2>() : WS.own.as<int2>(); out.g.lxy = P.scaled ? WS.lxy_s.as<int2>() : WS.lxy.as<int2>();
     return 0;
 }
 static inline bool is_coded(const DPolys& P) { return P.virt && !P.pts_ok; }
@@ -66,7 +66,7 @@ static inline bool is_coded(const DPolys& P) { return P.virt && !P.pts_ok; }
         else { const ESrc SRC = esrc_of(P); BODY }                                             \
     } while (0)
 template <class Cur> struct CurPt {
-    const Cur& c;
+    Cur& c;
     __device__ __forceinline__ vs::IPt operator()(int64_t i) const { const int2 p = c.at(i); return vs::IPt{p.x, p.y}; }
 };
 
@@ -75,7 +75,7 @@ template <class Src>
 __global__ __launch_bounds__(128) void k_poly_features(Src src, int64_t n_polys, int what, PolyFeat* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_polys) return;
-    const auto cu = src.cur(i);
+    auto cu = src.cur(i);
     int64_t n = src.len(i);
     PolyFeat f;
     const int2 pf = cu.at(0); int2 pl = n >= 1 ? cu.at(n - 1) : pf;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
         PolyFeat f = out[i];
         const int64_t n = f.n;                     // already the open view when requested
         if (n <= ORIP_LONG_POLY) continue;         // uniform for the block
-        const auto cu = src.cur(i);
+        auto cu = src.cur(i);
         auto P2 = [&](int64_t k) { return cu.at(k); };
         const int tid = threadIdx.x;
         int x0 = f.sx, x1 = f.sx, y0 = f.sy, y1 = f.sy; double arc = 0.0;
@@ -575,7 +575,7 @@ static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPol
     VSrc vs_; ORIP_TRY(vsrc_of(c, src, vs_));
     dst.n = n; dst.total = 0;
     dst.virt = true; dst.pts_ok = false; dst.vident = false; dst.vlayer = src.vlayer; dst.vepoch = src.vepoch;
-    dst.scaled = src.scaled; dst.sx = src.sx; dst.sy = src.sy; dst.dx = src.dx; dst.dy = src.dy;
+    dst.scaled = src.scaled; dst.vsepoch = src.vsepoch;
     HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
     if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     HIPC(c, dst.vview.ensure((size_t)n * sizeof(VView) + 64));

@@ -13,6 +13,16 @@ __global__ __launch_bounds__(256) void k_scale_pts(const int2* __restrict__ in, 
     }
 }
 
+// the log pixels in use (ent_idx[0 .. *n)), scaled
+__global__ __launch_bounds__(256) void k_scale_ents(const unsigned* __restrict__ ent_idx, const unsigned* __restrict__ n, const int2* __restrict__ in, int2* __restrict__ out,
+                                                     float sx, float sy, float dx, float dy) {
+    const unsigned m = *n;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const unsigned e = ent_idx[i]; const int2 p = in[e];
+        out[e] = make_int2((int)__fadd_rn(__fmul_rn((float)p.x, sx), dx), (int)__fadd_rn(__fmul_rn((float)p.y, sy), dy));
+    }
+}
+
 // explicit points of a walk-coded list, on request (orip_get_polys, consumers that read int32 pairs); enqueued on the calling lane's stream
 int orip_polys_materialize(orip_ctx* c, DPolys& P) {
     if (!is_coded(P)) return 0;
@@ -35,12 +45,24 @@ int orip_scale_vectors_impl(orip_ctx* c, int layer, float sx, float sy, float dx
     DPolys& S = c->polys[ORIP_SLOT_CONTOURS][layer]; DPolys& D = c->polys[ORIP_SLOT_SCALED][layer];
     D.n = S.n; D.total = S.total;
     if (is_coded(S) && !S.scaled) {
-        // walk-coded contours: the scaled list is the same walks with _scale_one applied wherever a point is generated (vsrc.h) -- no pass over the points
-        D.virt = true; D.pts_ok = false; D.vident = S.vident; D.vlayer = S.vlayer; D.vepoch = S.vepoch;
-        D.scaled = true; D.sx = sx; D.sy = sy; D.dx = dx; D.dy = dy;
+        // walk-coded contours: the scaled list is the same walks over scaled copies of the two small point tables (own points, log pixels) --
+        // _scale_one runs over ~1e6 distinct points of a heavy layer instead of its 2.8e8 list points
+        WalkStore& WS = c->wstore[S.vlayer];
+        if (S.vepoch != WS.epoch) ORIP_FAIL(c, "the walk records of layer %d behind CONTOURS have been replaced by a newer trace", S.vlayer);
+        HIPC(c, WS.own_s.ensure((size_t)std::max<int64_t>(WS.n_own, 1) * 8 + 64));
+        HIPC(c, WS.lxy_s.ensure(WS.lxy.cap));
+        WS.sx = sx; WS.sy = sy; WS.dx = dx; WS.dy = dy; WS.sepoch++;
+        {
+            ProfScope ps(c, "k_scale_pts");
+            if (WS.n_own) hipLaunchKernelGGL(k_scale_pts, dim3((unsigned)std::min<int64_t>(cdiv(WS.n_own, 256), 8192)), dim3(256), 0, LN(c).stream, WS.own.as<int2>(), WS.own_s.as<int2>(), WS.n_own, sx, sy, dx, dy);
+            hipLaunchKernelGGL(k_scale_ents, dim3((unsigned)std::min<int64_t>(cdiv(std::max<int64_t>(WS.ent_cap, 1), 256), 2048)), dim3(256), 0, LN(c).stream, WS.ent_idx.as<unsigned>(), WS.cnt.as<unsigned>(),
+                               WS.lxy.as<int2>(), WS.lxy_s.as<int2>(), sx, sy, dx, dy);
+        }
+        D.virt = true; D.pts_ok = false; D.vident = S.vident; D.vlayer = S.vlayer; D.vepoch = S.vepoch; D.scaled = true; D.vsepoch = WS.sepoch;
         HIPC(c, D.off.ensure((size_t)(S.n + 1) * 8 + 64));
         HIPC(c, hipMemcpyAsync(D.off.p, S.off.p, (size_t)(S.n + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         if (!S.vident) { HIPC(c, D.vview.ensure((size_t)std::max<int64_t>(S.n, 1) * sizeof(VView) + 64)); HIPC(c, hipMemcpyAsync(D.vview.p, S.vview.p, (size_t)S.n * sizeof(VView), hipMemcpyDeviceToDevice, LN(c).stream)); }
+        HIPC(c, hipGetLastError());
         if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
         return 0;
     }

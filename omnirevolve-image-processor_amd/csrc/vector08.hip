@@ -39,7 +39,7 @@ __global__ __launch_bounds__(128) void k_split_small08(Src src, int64_t n_polys,
                 per = (double)vs::pairwise_seglen_sum<0>(p, n);
                 if (per <= P.tap_max_per) vs::min_enclosing_circle(p, n, cx, cy, r);
             } else {                                  // a tap candidate has at most tap_max_v <= 64 vertices (checked by the host): private copy
-                const auto cu = src.cur(i);
+                auto cu = src.cur(i);
                 LocalPts<decltype(cu), 64> lp; lp.load(cu, (int)n);
                 per = (double)vs::pairwise_seglen_sum<0>(lp.xy, n);
                 if (per <= P.tap_max_per) vs::min_enclosing_circle(lp.xy, n, cx, cy, r);
@@ -77,7 +77,7 @@ template <class Src>
 __global__ __launch_bounds__(128) void k_cumlen(Src src, int64_t n_polys, double step, float* __restrict__ cum, RsInfo* __restrict__ info) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_polys) return;
-    const auto cu = src.cur(i); int64_t n = src.len(i);
+    auto cu = src.cur(i); int64_t n = src.len(i);
     float* s = cum + src.off[i];
     RsInfo r; r.n_eff = n; r.total = 0; r.m = 0; r.pass = 0;
     const int2 pf = cu.at(0);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, do
         RsInfo r = info[i];
         const int64_t n = r.n_eff;
         if (n <= ORIP_LONG_CUM) continue;
-        const auto cu = src.cur(i); float* s = cum + src.off[i];
+        auto cu = src.cur(i); float* s = cum + src.off[i];
         const int64_t nseg = n - 1;
         float acc = 0.f;
         if (lane == 0) s[0] = 0.f;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const float* __restric
     const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
     int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
     unsigned i = ord[r]; unsigned j = g - sbase[r];
-    const auto cu = src.cur(i); const float* s = cum + src.off[i];
+    auto cu = src.cur(i); const float* s = cum + src.off[i];
     RsInfo ri = info[i];
     double x, y;
     if (ri.pass) { const int2 q = cu.at(j); x = (double)(float)q.x; y = (double)(float)q.y; }

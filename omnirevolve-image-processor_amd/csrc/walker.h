@@ -58,6 +58,7 @@ struct WalkArgs {
     unsigned cap_factor;               // regions of component c (b = comp_start[c], fg = size): state log [F*b + 64*c, + F*fg + 64), step log [F*b + 256*c, + F*fg + 256)
     WalkInfo* winfo;                   // [2*M]
     int* overflow;                     // set when a region was too small (host retries with a larger cap_factor)
+    unsigned* log_used;                // optional: state-log entries of component c in use when its trace ended (the walk-coded lists read their pixels)
     // write pass
     const unsigned long long* pts_off; const unsigned* path_off;   // exclusive scans over winfo (len_kept, kept)
     unsigned long long layer_pts_base[ORIP_MAX_LAYERS]; unsigned layer_path_base[ORIP_MAX_LAYERS];
@@ -730,6 +731,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         else if (len >= 2 && close_to(W, s, wv.pl)) { flags = 1; len++; }
         finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
     }
+    if (A.log_used && wv.leader()) A.log_used[c] = logcur;
     if (over && wv.leader()) *A.overflow = 1;
     if (stalled && wv.leader()) *A.overflow = 2;                   // internal error: the host reports it instead of retrying
     if (A.dbg && wv.leader()) {
@@ -836,7 +838,7 @@ ORIP_HD inline void write_chunk(const WalkArgs& A, int layer, const unsigned* ke
 //                                     E(u) = ent_j + (u - u0_j) % lam_j   (lam_j  > 0, the closing cycle: always the last piece)
 // ------------------------------------------------------------------------------------------------
 struct VWalk { unsigned own_off, n_own, piece_off, n_piece, len, flags, pad0, pad1; };     // flags bit0: the last point is the start again (04:203-204)
-struct VPiece { unsigned u0, ent, lam, pad; };                                            // ent: index into the layer's log buffer
+struct VPiece { unsigned u0, ent, lam, magic; };                                          // ent: index into the layer's log buffer; magic = floor(2^32 / lam) for d % lam (vsrc.h)
 struct VView { unsigned wid, first, len, rev; };                                          // polyline = points first .. first+len-1 of walk wid, reversed if rev
 
 // pieces of the tail of a kept walk; emit(j, u0, entry, lam) with GLOBAL entry indices (as the trace addressed the log).  Returns their number.
