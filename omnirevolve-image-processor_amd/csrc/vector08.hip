@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const float* __restric
     A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
     bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
     A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
-    ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g;
+    if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
 }
 
 // distance of every sample to its predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, do
 // is not held up by one lane that has to search.
 __global__ __launch_bounds__(256) void k_accept_pre(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, unsigned MS,
                                                      const unsigned* __restrict__ firstseq, int W, int2* __restrict__ spt, uint8_t* __restrict__ sflag,
-                                                     unsigned* __restrict__ surv, unsigned* __restrict__ n_surv) {
+                                                     unsigned* __restrict__ surv, unsigned* __restrict__ n_surv, unsigned long long* __restrict__ work) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
-    bool need = false;
+    bool need = false; unsigned mynp = 0;
     if (g < MS) {
         unsigned r = A.rank[g], b = sbase[r], j = g - b;
         bool ok = A.inc[g] != 0;
@@ -429,15 +429,42 @@ __global__ __launch_bounds__(256) void k_accept_pre(SampleArrs A, const unsigned
         if (ok && firstseq[(size_t)A.yi[g] * W + A.xi[g]] < limit) ok = false;
         spt[g] = make_int2((int)A.sx[g], (int)A.sy[g]);
         sflag[g] = (ok ? 1 : 0) | (j == 0 ? 2 : 0);
-        need = ok && np > 0;
+        need = ok && np > 0; mynp = need ? np : 0u;
     }
     const unsigned long long m = __ballot(need);
     if (m) {
         const int lane = threadIdx.x & 63;
+        unsigned long long wsum = mynp;                    // popped own samples the survivors of this wave have to be compared with
+        for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(n_surv, (unsigned)__popcll(m));
+        if (lane == 0) { base = atomicAdd(n_surv, (unsigned)__popcll(m)); atomicAdd(work, wsum); }
         base = (unsigned)__shfl((int)base, 0, 64);
         if (need) surv[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = g;
+    }
+}
+// _PointHash.near without the hash: a survivor is compared with ALL popped samples of its own polyline, 64 at a time.  Equal to the
+// hash answer whenever the cell is at least the radius (every point within R then lies in the 3 x 3 cells the reference looks at), and
+// cheap whenever the survivors are few and early in their polylines -- the bench image: 56 k survivors of 7.4e7 samples, all within
+// the first lap of their walk; the bucket sort of ALL samples this replaces was the largest kernel of stage 08-A.  The host picks
+// this path from the work sum k_accept_pre leaves (sum of popped samples over the survivors) and keeps the sorted buckets otherwise.
+__global__ __launch_bounds__(256) void k_accept_brute(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, double R2,
+                                                       const unsigned* __restrict__ surv, const unsigned* __restrict__ n_surv, uint8_t* __restrict__ sflag) {
+    const unsigned ns = *n_surv;
+    const int lane = threadIdx.x & 63;
+    for (unsigned t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ns; t += gridDim.x * 4) {
+        const unsigned g = surv[t];
+        const unsigned b = sbase[A.rank[g]], np = npop[g];
+        const double x = A.sx[g], y = A.sy[g];
+        bool rej = false;
+        for (unsigned q0 = 0; q0 < np && !rej; q0 += 64) {
+            const unsigned q = q0 + (unsigned)lane; bool hit = false;
+            if (q < np) {
+                double ddx = __dsub_rn(A.sx[b + q], x), ddy = __dsub_rn(A.sy[b + q], y);
+                hit = __dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)) <= R2;
+            }
+            if (__ballot(hit)) rej = true;
+        }
+        if (rej && lane == 0) sflag[g] &= (uint8_t)~1u;
     }
 }
 // one wavefront per survivor: 65-ary lower-bound searches and 64-wide scans of the three buckets of a column (they are neighbours in
@@ -1136,7 +1163,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
             int2* hints = (int2*)(LN(c).vtmp[5].as<uint8_t>() + (((size_t)MS * 24 + 63) & ~(size_t)63));
             hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), cum, info, ord, sbase, nk, MS, step, nb, hints);
-            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, ckin, cvin, hints); }); }
+            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints); }); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
@@ -1192,24 +1219,36 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             }
             { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tab, tsize, P.brush_forbid / 2, firstseq, W, H); }
             tick("caps");
-            // ---- A5: (polyline, cell) buckets in pop order
-            {
-                ProfScope ps(c, "sort_cells");
-                size_t bytes = 0;
-                HIPC(c, rocprim::segmented_radix_sort_pairs(nullptr, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
-                HIPC(c, LN(c).tmpF.ensure(bytes + 16));
-                HIPC(c, rocprim::segmented_radix_sort_pairs(LN(c).tmpF.p, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
-            }
-            tick("cells");
-            // ---- A6
+            // ---- A5 / A6: cheap test of every sample, then _PointHash.near for the survivors
             {
                 HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));       // pop counts of the redone polylines
-                unsigned* surv = ckin;                                           // the unsorted keys are no longer needed
-                unsigned* d_ns = LN(c).flags.as<unsigned>() + 60;
+                unsigned* surv = LN(c).vtmp[8].as<unsigned>();                  // (the scan results kept there have been consumed by k_capprev)
+                unsigned* d_ns = LN(c).flags.as<unsigned>() + 60;               // survivor count; the work sum is an 8-byte word of its own
+                unsigned long long* d_work = reinterpret_cast<unsigned long long*>(LN(c).flags.as<unsigned>() + 124);
                 HIPC(c, hipMemsetAsync(d_ns, 0, 4, LN(c).stream));
-                ProfScope ps(c, "k_accept");
-                hipLaunchKernelGGL(k_accept_pre, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, firstseq, W, spt, sflag, surv, d_ns);
-                hipLaunchKernelGGL(k_accept, dim3((unsigned)std::min<unsigned>(cdiv(MS, 256), 16384u)), dim3(256), 0, LN(c).stream, A, sbase, npop, inv, P.col_rad * P.col_rad, ckout, cvout, surv, d_ns, sflag);
+                HIPC(c, hipMemsetAsync(d_work, 0, 8, LN(c).stream));
+                { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept_pre, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, firstseq, W, spt, sflag, surv, d_ns, d_work); }
+                unsigned long long h_work = 0; ORIP_TRY(vread(c, &h_work, d_work));
+                const double R2 = P.col_rad * P.col_rad;
+                // without the hash when it gives the hash's answer (cell >= radius) and costs less than sorting every sample into buckets
+                const bool brute = cell >= P.col_rad && h_work <= 64ull * (unsigned long long)MS && !getenv("ORIP_HASH_SORT");
+                if (tdbg) { char b2[64]; snprintf(b2, sizeof b2, " [near work %llu %s]", h_work, brute ? "direct" : "buckets"); tlog += b2; }
+                if (brute) {
+                    ProfScope ps(c, "k_accept");
+                    hipLaunchKernelGGL(k_accept_brute, dim3((unsigned)std::min<unsigned>(cdiv(MS, 256), 16384u)), dim3(256), 0, LN(c).stream, A, sbase, npop, R2, surv, d_ns, sflag);
+                } else {
+                    // (polyline, cell) buckets in pop order: the samples of a polyline are contiguous, so its hash is its own range sorted by cell key
+                    hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, MS, inv, ckin, cvin);
+                    {
+                        ProfScope ps(c, "sort_cells");
+                        size_t bytes = 0;
+                        HIPC(c, rocprim::segmented_radix_sort_pairs(nullptr, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
+                        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+                        HIPC(c, rocprim::segmented_radix_sort_pairs(LN(c).tmpF.p, bytes, ckin, ckout, cvin, cvout, (unsigned)MS, (unsigned)nk, sbase, sbase + 1, 0u, 32u, LN(c).stream));
+                    }
+                    ProfScope ps(c, "k_accept");
+                    hipLaunchKernelGGL(k_accept, dim3((unsigned)std::min<unsigned>(cdiv(MS, 256), 16384u)), dim3(256), 0, LN(c).stream, A, sbase, npop, inv, R2, ckout, cvout, surv, d_ns, sflag);
+                }
             }
             HIPC(c, hipGetLastError());
             tick("accept");

@@ -219,8 +219,10 @@ def test_stage08_tail_simulation_both_forms(dev, monkeypatch):
         if seq:
             monkeypatch.setenv("ORIP_TAIL_SEQ", "1")
             monkeypatch.setenv("ORIP_CAPS_TINY", "1")      # and the capsule table starts too small: growth path
+            monkeypatch.setenv("ORIP_HASH_SORT", "1")      # and _PointHash.near through the sorted buckets instead of the direct comparison
         else:
             monkeypatch.delenv("ORIP_TAIL_SEQ", raising=False)
+            monkeypatch.delenv("ORIP_HASH_SORT", raising=False)
         got_l, got_t = S.dedup_layer(polys, cfg, dev)
         assert got_t == want_t, seq
         assert same_polys(got_l, want_l), (seq, len(got_l), len(want_l))
