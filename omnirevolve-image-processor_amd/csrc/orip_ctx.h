@@ -68,8 +68,9 @@ struct DPolys {
     int vlayer = 0;             // whose WalkStore
     uint64_t vepoch = 0;        // WalkStore::epoch the list was built on: a later trace of the layer makes it stale
     uint64_t vsepoch = 0;       // scaled lists: WalkStore::sepoch of the scaled tables they read
+    uint64_t pf_tag = 0;        // != 0: the list is a permutation-with-flips of the list LaneRes::pf08 (same tag) was computed on
     bool scaled = false;        // reads the scaled tables of the WalkStore
-    void set_explicit() { virt = false; pts_ok = true; }
+    void set_explicit() { virt = false; pts_ok = true; pf_tag = 0; }
 };
 // What stage 04 leaves per layer (raster04.hip: trace_finish) and every walk-coded list of the layer reads
 struct WalkStore {
@@ -101,6 +102,12 @@ struct LaneRes {
     DBuf vtmp[12], tmpE, tmpF, flags, canvas;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DPolys tp[6];   // persistent temporaries of the vector stages (no hipFree in steady state: hipFree synchronises the device)
+    // stage 08's order-independent front, computed on the side stream while stage 07's greedy chain runs (vector08.hip: prefetch08)
+    struct Prefetch08 {
+        bool valid = false; uint64_t tag = 0; int64_t n = 0; int64_t tot_f = 0; double step = 0;
+        DPolys fwd_open, rev;          // the views the cumulative lengths were taken over: opened forward polylines, reversed polylines
+        DBuf feat, info, cum, ord;     // PolyFeat[2n] / RsInfo[2n]: forward at i, reversed at n + i; cum: forward list, then reversed list
+    } pf08;
 };
 extern thread_local int orip_tls_lane;
 #define LN(c) ((c)->ln[orip_tls_lane])
@@ -196,6 +203,7 @@ int orip_raster02_lab_tables(orip_ctx* c);
 // the per-layer stages without the closing stream wait (orip_layer_front chains them on the layer's stream)
 int orip_contours_layer_impl(orip_ctx* c, int layer, bool sync);
 int orip_scale_vectors_impl(orip_ctx* c, int layer, float sx, float sy, float dx, float dy, bool sync);
-int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync);
+int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync, const orip_params08* prm_for_prefetch = nullptr);
+int orip_prefetch08(orip_ctx* c, void* prm, DPolys& scaled, const void* feat07);
 // explicit points of a walk-coded list (no-op for explicit lists); on the calling lane's stream, not synchronised (vector.hip)
 int orip_polys_materialize(orip_ctx* c, DPolys& P);

@@ -575,7 +575,7 @@ static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPol
     VSrc vs_; ORIP_TRY(vsrc_of(c, src, vs_));
     dst.n = n; dst.total = 0;
     dst.virt = true; dst.pts_ok = false; dst.vident = false; dst.vlayer = src.vlayer; dst.vepoch = src.vepoch;
-    dst.scaled = src.scaled; dst.vsepoch = src.vsepoch;
+    dst.scaled = src.scaled; dst.vsepoch = src.vsepoch; dst.pf_tag = src.pf_tag;      // the views keep naming the source's walks: what was computed per walk and direction stays addressable
     HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
     if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     HIPC(c, dst.vview.ensure((size_t)n * sizeof(VView) + 64));
@@ -799,7 +799,11 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
 }
 
 // Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
-static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
+// under_greedy (optional): called right after the greedy kernel has been enqueued, with the features of the source list (device
+// array, complete: the host has read the seed).  The chain of greedy steps keeps ONE wave busy for milliseconds, so work that does not
+// depend on the order can be issued to the lane's side stream from there (stage 08's front: vector08.hip: prefetch08).
+typedef int (*ReorderHook)(orip_ctx* c, void* arg, DPolys& src, const PolyFeat* feat);
+static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook under_greedy = nullptr, void* hook_arg = nullptr) {
     int64_t n = src.n;
     if (n == 0) { dst.n = 0; dst.total = 0; dst.set_explicit(); HIPC(c, dst.off.ensure(64)); HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     if (n > 0x7fffffff) ORIP_FAIL(c, "too many polylines");
@@ -845,6 +849,7 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind) {
         ProfScope ps(c, "k_greedy_nn");
         hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips);
     }
+    if (under_greedy) ORIP_TRY(under_greedy(c, hook_arg, src, feat));
     hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
     HIPC(c, hipGetLastError());
     return vgather_list(c, desc, n, src, dst);

@@ -86,10 +86,15 @@ extern "C" int orip_scale_vectors(orip_ctx* c, int layer, float sx, float sy, fl
     return orip_scale_vectors_impl(c, layer, sx, sy, dx, dy, true);
 }
 
-int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync) {
+static int hook_prefetch08(orip_ctx* c, void* arg, DPolys& src, const PolyFeat* feat) { return orip_prefetch08(c, arg, src, feat); }
+int orip_sort_contours_impl(orip_ctx* c, int layer, bool sync, const orip_params08* prm_for_prefetch) {
     if (layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad layer %d", layer);
     ORIP_LANE(c, layer + 1);
-    ORIP_TRY(vreorder(c, c->polys[ORIP_SLOT_SCALED][layer], c->polys[ORIP_SLOT_SORTED][layer], 7));
+    LN(c).pf08.valid = false;
+    DPolys& S = c->polys[ORIP_SLOT_SCALED][layer]; DPolys& D = c->polys[ORIP_SLOT_SORTED][layer];
+    const bool pf = prm_for_prefetch && is_coded(S) && S.vident && S.n > 0 && !getenv("ORIP_NO_PREFETCH08");
+    ORIP_TRY(vreorder(c, S, D, 7, pf ? hook_prefetch08 : nullptr, (void*)prm_for_prefetch));
+    if (pf && LN(c).pf08.valid) D.pf_tag = LN(c).pf08.tag;
     if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }

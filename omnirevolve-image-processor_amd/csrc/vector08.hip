@@ -173,7 +173,7 @@ __device__ __forceinline__ int64_t sample_seg(const float* __restrict__ s, int64
     int64_t k = lo - 1; if (k < 0) k = 0; if (k > n_eff - 2) k = n_eff - 2;
     return k;
 }
-__global__ __launch_bounds__(256) void k_sample_hints(const int64_t* __restrict__ off, const float* __restrict__ cum, const RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
+__global__ __launch_bounds__(256) void k_sample_hints(const int64_t* __restrict__ off /* where polyline i's cumulative lengths start in cum */, const float* __restrict__ cum, const RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
                                                        const unsigned* __restrict__ sbase, int64_t n_rank, unsigned MS, double step, unsigned nb, int2* __restrict__ hints) {
     unsigned b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nb) return;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_sample_hints(const int64_t* __restrict_
     hints[b] = make_int2((int)r, (int)k);
 }
 template <class Src>
-__global__ __launch_bounds__(256) void k_samples(Src src, const float* __restrict__ cum,
+__global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restrict__ cumoff, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
                                                   const int2* __restrict__ hints) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const float* __restric
     const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
     int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
     unsigned i = ord[r]; unsigned j = g - sbase[r];
-    auto cu = src.cur(i); const float* s = cum + src.off[i];
+    auto cu = src.cur(i); const float* s = cum + cumoff[i];
     RsInfo ri = info[i];
     double x, y;
     if (ri.pass) { const int2 q = cu.at(j); x = (double)(float)q.x; y = (double)(float)q.y; }
@@ -1054,6 +1054,83 @@ __global__ __launch_bounds__(256) void k_concat_taps(const int2* a, int64_t na, 
     if (i < na) out[i] = a[i]; else if (i < na + nb) out[i] = b[i - na];
 }
 
+// ================================================================= prefetch of the order-independent part of the front (under stage 07's greedy)
+// Stage 07 only permutes and flips the scaled contours (07:55-95), and it does so with a serial chain of greedy steps that keeps one
+// wavefront busy for milliseconds.  What stage 08 computes PER POLYLINE before anything depends on the order -- bounding box and numpy
+// perimeter of the opened polyline (A0 / A1), its float32 cumulative lengths and sample count (A2) -- depends on the direction the
+// polyline is read in, nothing else.  So both directions are computed on the lane's side stream while the chain runs, and stage 08
+// picks per polyline by stage 07's flip flag.  (Closed contours are never flipped, 07:60-62: their reversed entries are unused.)
+__global__ __launch_bounds__(256) void k_pf_views(const PolyFeat* __restrict__ feat07, const int64_t* __restrict__ off, int64_t n, VView* __restrict__ vf, VView* __restrict__ vr,
+                                                   int64_t* __restrict__ lf, int64_t* __restrict__ lr) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == n) { lf[i] = 0; lr[i] = 0; }
+    if (i >= n) return;
+    const unsigned len = (unsigned)(off[i + 1] - off[i]);
+    VView a; a.wid = (unsigned)i; a.first = 0u; a.len = (feat07[i].closed && len > 0u) ? len - 1u : len; a.rev = 0u;     // _ensure_open (08:48-51), as split_small leaves the kept polylines
+    VView b; b.wid = (unsigned)i; b.first = 0u; b.len = len; b.rev = 1u;
+    vf[i] = a; vr[i] = b; lf[i] = a.len; lr[i] = b.len;
+}
+__global__ __launch_bounds__(256) void k_pf_pick_feat(const VView* __restrict__ sview, int64_t n, const PolyFeat* __restrict__ pf, int64_t npf, PolyFeat* __restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) { const VView v = sview[k]; out[k] = pf[v.rev ? npf + (int64_t)v.wid : (int64_t)v.wid]; }
+}
+__global__ __launch_bounds__(256) void k_pf_pick_info(const VView* __restrict__ kview, int64_t nk, const RsInfo* __restrict__ pinfo, int64_t npf, const int64_t* __restrict__ off_f,
+                                                       const int64_t* __restrict__ off_r, int64_t tot_f, RsInfo* __restrict__ info, int64_t* __restrict__ cumoff) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nk) return;
+    const VView v = kview[j];
+    info[j] = pinfo[v.rev ? npf + (int64_t)v.wid : (int64_t)v.wid];
+    cumoff[j] = v.rev ? tot_f + off_r[v.wid] : off_f[v.wid];
+}
+struct StreamSwap {       // everything issued while this lives goes to the lane's side stream
+    LaneRes& l;
+    explicit StreamSwap(LaneRes& lane) : l(lane) { std::swap(l.stream, l.stream2); }
+    ~StreamSwap() { std::swap(l.stream, l.stream2); }
+};
+static std::atomic<uint64_t> g_pf_tag{1};
+static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const PolyFeat* feat07) {
+    LaneRes::Prefetch08& F = LN(c).pf08;
+    F.valid = false;
+    const int64_t n = S.n, total = S.total;
+    if (n <= 0 || total <= 0 || total > 0x3fffffff) return 0;
+    const double step = std::max(1.0, P.sample_step);
+    HIPC(c, F.feat.ensure((size_t)2 * n * sizeof(PolyFeat) + 64));
+    HIPC(c, F.info.ensure((size_t)2 * n * sizeof(RsInfo) + 64));
+    HIPC(c, F.cum.ensure((size_t)2 * total * 4 + 64));
+    HIPC(c, F.ord.ensure((size_t)n * 16 + 64));
+    for (DPolys* L : {&F.fwd_open, &F.rev}) {
+        L->n = n; L->total = total; L->virt = true; L->pts_ok = false; L->vident = false; L->vlayer = S.vlayer; L->vepoch = S.vepoch; L->scaled = S.scaled; L->vsepoch = S.vsepoch; L->pf_tag = 0;
+        HIPC(c, L->off.ensure((size_t)(n + 1) * 8 + 64)); HIPC(c, L->vview.ensure((size_t)n * sizeof(VView) + 64));
+    }
+    HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 16 + 64));
+    {
+        StreamSwap sw(LN(c));                       // LN(c).stream is the side stream from here to the end of the block
+        int64_t* lf = LN(c).tmpE.as<int64_t>(); int64_t* lr = lf + (n + 1);
+        hipLaunchKernelGGL(k_pf_views, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, feat07, S.off.as<int64_t>(), n, F.fwd_open.vview.as<VView>(), F.rev.vview.as<VView>(), lf, lr);
+        ORIP_TRY(vscan_excl<int64_t>(c, lf, F.fwd_open.off.as<int64_t>(), (size_t)n + 1));
+        ORIP_TRY(vscan_excl<int64_t>(c, lr, F.rev.off.as<int64_t>(), (size_t)n + 1));
+        PolyFeat* ff = F.feat.as<PolyFeat>(); RsInfo* inf = F.info.as<RsInfo>(); float* cum = F.cum.as<float>();
+        VSrc sS, sF, sR; ORIP_TRY(vsrc_of(c, S, sS)); ORIP_TRY(vsrc_of(c, F.fwd_open, sF)); ORIP_TRY(vsrc_of(c, F.rev, sR));
+        // A0 / A1: features of the opened polyline in both directions (the forward ones over the scaled list itself, as split_small does)
+        ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16, ff));
+        ORIP_TRY(vfeatures_src(c, sR, n, total, 1 | 16, ff + n));
+        // A2: cumulative lengths; long polylines longest first
+        unsigned* kin = F.ord.as<unsigned>(); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* ordl = vin + n;
+        hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
+        ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
+        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sF, n, step, cum, inf);
+                                        hipLaunchKernelGGL(k_cumlen<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sR, n, step, cum + total, inf + n); }
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long");
+            hipLaunchKernelGGL(k_cumlen_long<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sF, n, step, cum, inf, ordl);
+            hipLaunchKernelGGL(k_cumlen_long<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sR, n, step, cum + total, inf + n, ordl); }
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream));
+    }
+    HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));      // the main stream (behind the greedy kernel) goes on when both are done
+    F.valid = true; F.tag = g_pf_tag.fetch_add(1); F.n = n; F.tot_f = total; F.step = step;
+    return 0;
+}
+
 // split_small_and_taps on a DPolys -> kept (opened) + taps appended to tapbuf at tap_base
 __global__ __launch_bounds__(256) void k_compact_feat(const unsigned* __restrict__ flag, const unsigned* __restrict__ scan, int64_t n, const PolyFeat* __restrict__ in, PolyFeat* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1072,7 +1149,10 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     HIPC(c, LN(c).vtmp[10].ensure((size_t)n * sizeof(PolyFeat) + 64));
     PolyFeat* sfeat = LN(c).vtmp[10].as<PolyFeat>();
     if (is_coded(src) && P.tap_max_v > 64) ORIP_TRY(orip_polys_materialize(c, src));      // the walk-coded tap test copies <= 64 vertices (default tap_max_vertices: 50)
-    ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat));
+    const LaneRes::Prefetch08& F = LN(c).pf08;
+    if (kept_feat && is_coded(src) && src.pf_tag && F.valid && F.tag == src.pf_tag && !src.vident)        // computed under stage 07's greedy, per walk and direction
+        hipLaunchKernelGGL(k_pf_pick_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.vview.as<VView>(), n, F.feat.as<PolyFeat>(), F.n, sfeat);
+    else ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat));
     { ProfScope ps(c, "k_split_small08"); ORIP_WITH_SRC(c, src, sv, { hipLaunchKernelGGL(k_split_small08<decltype(sv)>, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, sv, n, P, sfeat, is_tap, is_keep, tap_xy, kd); }); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
@@ -1099,6 +1179,10 @@ __global__ __launch_bounds__(256) void k_fill_per(const PolyFeat* __restrict__ f
 
 
 }  // namespace
+
+int orip_prefetch08(orip_ctx* c, void* prm, DPolys& scaled, const void* feat07) {
+    return prefetch08(c, *static_cast<const orip_params08*>(prm), scaled, static_cast<const PolyFeat*>(feat07));
+}
 
 extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm) {
     orip_enter(c);
@@ -1141,11 +1225,19 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         ORIP_TRY((vsort_pairs<float, unsigned>(c, kin, kout, vin, ord, (size_t)nk, 0, 32, true)));
         tick("A0-1");
         // ---- A2: resample
-        HIPC(c, LN(c).vtmp[1].ensure((size_t)kept0.p.total * 4 + 64));
-        float* cum = LN(c).vtmp[1].as<float>();
         const double step = std::max(1.0, P.sample_step);
+        const LaneRes::Prefetch08& F = LN(c).pf08;
+        const bool picked = is_coded(kept0.p) && kept0.p.pf_tag && F.valid && F.tag == kept0.p.pf_tag && F.step == step && !kept0.p.vident;
+        HIPC(c, LN(c).vtmp[1].ensure((picked ? 0 : (size_t)kept0.p.total * 4) + (size_t)(nk + 1) * 8 + 128));
+        int64_t* cumoff = LN(c).vtmp[1].as<int64_t>(); float* cum = reinterpret_cast<float*>(cumoff + (nk + 2));
+        if (picked) {       // cumulative lengths and sample counts were taken under stage 07's greedy, per walk and direction: pick this list's
+            cum = F.cum.as<float>();
+            hipLaunchKernelGGL(k_pf_pick_info, dim3(cdiv(nk, 256)), dim3(256), 0, LN(c).stream, kept0.p.vview.as<VView>(), nk, F.info.as<RsInfo>(), F.n, F.fwd_open.off.as<int64_t>(), F.rev.off.as<int64_t>(), F.tot_f, info, cumoff);
+        } else {
+        HIPC(c, hipMemcpyAsync(cumoff, kept0.p.off.p, (size_t)(nk + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
         if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen_long<decltype(sv)>, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
+        }
         tick("cumlen");
         hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
@@ -1162,8 +1254,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
             int2* hints = (int2*)(LN(c).vtmp[5].as<uint8_t>() + (((size_t)MS * 24 + 63) & ~(size_t)63));
-            hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, kept0.p.off.as<int64_t>(), cum, info, ord, sbase, nk, MS, step, nb, hints);
-            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints); }); }
+            hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, cumoff, cum, info, ord, sbase, nk, MS, step, nb, hints);
+            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints); }); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
@@ -1442,7 +1534,7 @@ extern "C" int orip_layer_front(orip_ctx* c, int layer, float sx, float sy, floa
     if (upto >= 8 && !prm) ORIP_FAIL(c, "stage 08 needs its parameters");
     ORIP_TRY(orip_contours_layer_impl(c, layer, false));
     ORIP_TRY(orip_scale_vectors_impl(c, layer, sx, sy, dx, dy, upto < 7));
-    if (upto >= 7) ORIP_TRY(orip_sort_contours_impl(c, layer, upto < 8));
+    if (upto >= 7) ORIP_TRY(orip_sort_contours_impl(c, layer, upto < 8, upto >= 8 ? prm : nullptr));
     if (upto >= 8) ORIP_TRY(orip_dedup_layer(c, layer, prm));
     return 0;
 }

@@ -28,3 +28,9 @@ for l in range(K):
     r_sizes = np.bincount(r_lab.ravel())[1:]
     print(f"layer {l}: {int(sk.sum())} px, {n} components; largest {int(sizes.max())} px: degree histogram {h_big.tolist()}, "
           f"{r_n} degree-2 groups (mean {r_sizes.mean():.1f}, median {int(np.median(r_sizes))}, max {int(r_sizes.max())}); all components: {h_all.tolist()}", flush=True)
+    tot2 = int(r_sizes.sum())
+    print("   degree-2 pixels of the largest component in groups of >= 8 / 16 / 32 / 64 / 128 px: " +
+          " / ".join(f"{100.0 * r_sizes[r_sizes >= t].sum() / max(tot2, 1):.0f}%" for t in (8, 16, 32, 64, 128)) + f" of {tot2}", flush=True)
+    if os.environ.get("ORIP_SAVE_BIG") and sizes.max() > 20000:
+        ys, xs = np.nonzero(m)
+        np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"bigcomp_l{l}.npz"), ys=ys.astype(np.int32), xs=xs.astype(np.int32), shape=np.array(sk.shape))
