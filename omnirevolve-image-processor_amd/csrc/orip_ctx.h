@@ -105,8 +105,8 @@ struct LaneRes {
     // stage 08's order-independent front, computed on the side stream while stage 07's greedy chain runs (vector08.hip: prefetch08)
     struct Prefetch08 {
         bool valid = false; uint64_t tag = 0; int64_t n = 0; int64_t tot_f = 0; double step = 0;
-        DPolys fwd_open, rev;          // the views the cumulative lengths were taken over: opened forward polylines, reversed polylines
-        DBuf feat, info, cum, ord;     // PolyFeat[2n] / RsInfo[2n]: forward at i, reversed at n + i; cum: forward list, then reversed list
+        const int64_t* src_off = nullptr;   // offsets of the list it was computed on (device): both readings of polyline i keep their cumulative lengths at src_off[i]
+        DBuf feat, info, cum, ord;     // PolyFeat[n] + reversed perimeters float[n]; RsInfo[2n]: forward at i, reversed at n + i; cum: forward readings, then (tot_f on) reversed
     } pf08;
 };
 extern thread_local int orip_tls_lane;

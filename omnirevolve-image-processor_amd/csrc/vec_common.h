@@ -71,8 +71,14 @@ template <class Cur> struct CurPt {
 };
 
 // what: bit0 perimeter KIND0, bit1 perimeter KIND1 (hypot), bit2 arcLength closed, bit3 arcLength open, bit4 open view (_ensure_open)
+// the reversed polyline as a point getter (pt(i) = point n - 1 - i)
+template <class Cur> struct RevPt {
+    Cur& c; int64_t n;
+    __device__ __forceinline__ vs::IPt operator()(int64_t i) const { const int2 p = c.at(n - 1 - i); return vs::IPt{p.x, p.y}; }
+};
+// what: ... bit5 (with bit0): per_rev[i] = the same perimeter over the REVERSED open polyline (numpy's pairwise sum depends on the order)
 template <class Src>
-__global__ __launch_bounds__(128) void k_poly_features(Src src, int64_t n_polys, int what, PolyFeat* __restrict__ out) {
+__global__ __launch_bounds__(128) void k_poly_features(Src src, int64_t n_polys, int what, PolyFeat* __restrict__ out, float* __restrict__ per_rev) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_polys) return;
     auto cu = src.cur(i);
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(128) void k_poly_features(Src src, int64_t n_polys,
     f.x0 = x0; f.y0 = y0; f.x1 = x1; f.y1 = y1;
     const CurPt<decltype(cu)> pt{cu};
     if (what & 1) f.per = vs::pairwise_seglen_sum_p<0>(pt, n);
+    if ((what & 33) == 33) { const RevPt<decltype(cu)> rp{cu, n}; per_rev[i] = vs::pairwise_seglen_sum_p<0>(rp, n); }
     if (what & 2) f.per = vs::pairwise_seglen_sum_p<1>(pt, n);
     if (what & 4) f.arc = vs::arc_length_p(pt, n, true);
     if (what & 8) f.arc = vs::arc_length_p(pt, n, false);
@@ -136,13 +143,26 @@ __global__ __launch_bounds__(256) void k_len_keys(const int64_t* __restrict__ of
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) { int64_t m = off[i + 1] - off[i]; key[i] = (unsigned)(m > 0xffffffffLL ? 0xffffffffLL : m); val[i] = (unsigned)i; }
 }
+// leaf of the REVERSED sequence: element i' of the reversed polyline's segment lengths is forward segment ns - 1 - i'
+__device__ __forceinline__ float pairwise_leaf_g8_rev(const int32_t* xy, int64_t ns, int64_t s, int64_t n, int j) {
+    auto el = [&](int64_t i) { return vs::seg_len_f32(xy, ns - 1 - (s + i)); };
+    const int64_t lim = n - (n % 8);
+    float r = el(j);
+    for (int64_t i = 8 + j; i < lim; i += 8) r += el(i);
+    r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+    for (int64_t i = lim; i < n; i++) r += el(i);
+    return r;
+}
+#define ORIP_PF_MARGIN 132      // points staged on either side of a turn's 2048: a leaf has at most 128 elements and owns a multiple of 64 of the turn
 template <class Src>
 __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_polys, int what,
-                                                             PolyFeat* __restrict__ out, float* __restrict__ leafbuf, const unsigned* __restrict__ order) {
+                                                             PolyFeat* __restrict__ out, float* __restrict__ leafbuf, const unsigned* __restrict__ order,
+                                                             float* __restrict__ per_rev, float* __restrict__ leafbuf_rev) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
     __shared__ float part[2 << ORIP_PW_DEPTH];
-    __shared__ int2 stage[2048 + 64 + 130 + 8];
+    __shared__ int2 stage[2048 + 2 * ORIP_PF_MARGIN + 8];
+    const bool want_rev = (what & 33) == 33;
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = order[rr];               // longest first: a block that draws a long polyline late would be the tail of the launch
         PolyFeat f = out[i];
@@ -152,18 +172,9 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
         auto P2 = [&](int64_t k) { return cu.at(k); };
         const int tid = threadIdx.x;
         int x0 = f.sx, x1 = f.sx, y0 = f.sy, y1 = f.sy; double arc = 0.0;
-        const bool closed_arc = (what & 4) != 0, any_arc = (what & 12) != 0;
-        if (!any_arc) {
-            // bounding box only: four independent 8-byte loads per turn keep the memory pipeline busy (the loop is latency-bound otherwise)
-            int64_t k = tid;
-            for (; k + 768 < n; k += 1024) {
-                const int2 a = P2(k), b = P2(k + 256), cc = P2(k + 512), d = P2(k + 768);
-                x0 = min(min(x0, a.x), min(min(b.x, cc.x), d.x)); x1 = max(max(x1, a.x), max(max(b.x, cc.x), d.x));
-                y0 = min(min(y0, a.y), min(min(b.y, cc.y), d.y)); y1 = max(max(y1, a.y), max(max(b.y, cc.y), d.y));
-            }
-            for (; k < n; k += 256) { const int2 a = P2(k); x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
-        } else {
-            // arc length next to the bounding box: the same four-loads-in-flight shape; a thread adds its terms in the order of its k
+        const bool closed_arc = (what & 4) != 0, any_arc = (what & 12) != 0, any_per = (what & 3) != 0;
+        if (any_arc) {
+            // arc length next to the bounding box: four loads in flight per thread; a thread adds its terms in the order of its k
             auto seg = [&](int64_t k, const int2 a, const int2 b) {       // b: predecessor of point k
                 x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y);
                 float dx = (float)a.x - (float)b.x, dy = (float)a.y - (float)b.y;
@@ -177,43 +188,71 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                 seg(k, a0, b0); seg(k + 256, a1, b1); seg(k + 512, a2, b2); seg(k + 768, a3, b3);
             }
             for (; k < n; k += 256) seg(k, P2(k), P2(pred(k)));
+        } else if (!any_per) {
+            // bounding box only: four independent 8-byte loads per turn keep the memory pipeline busy (the loop is latency-bound otherwise)
+            int64_t k = tid;
+            for (; k + 768 < n; k += 1024) {
+                const int2 a = P2(k), b = P2(k + 256), cc = P2(k + 512), d = P2(k + 768);
+                x0 = min(min(x0, a.x), min(min(b.x, cc.x), d.x)); x1 = max(max(x1, a.x), max(max(b.x, cc.x), d.x));
+                y0 = min(min(y0, a.y), min(min(b.y, cc.y), d.y)); y1 = max(max(y1, a.y), max(max(b.y, cc.y), d.y));
+            }
+            for (; k < n; k += 256) { const int2 a = P2(k); x0 = min(x0, a.x); x1 = max(x1, a.x); y0 = min(y0, a.y); y1 = max(y1, a.y); }
         }
-        rx0[tid] = x0; rx1[tid] = x1; ry0[tid] = y0; ry1[tid] = y1; rarc[tid] = arc;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) { rx0[tid] = min(rx0[tid], rx0[tid + s]); rx1[tid] = max(rx1[tid], rx1[tid + s]); ry0[tid] = min(ry0[tid], ry0[tid + s]); ry1[tid] = max(ry1[tid], ry1[tid + s]); rarc[tid] += rarc[tid + s]; }
-            __syncthreads();
-        }
-        float per = 0.f;
-        if (what & 3) {
+        float per = 0.f, perR = 0.f;
+        if (any_per) {
             const int64_t ns = n - 1;               // number of segments
             float* ls = leafbuf + (src.off[i] >> 6) + 2 * i;
-            const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group and turn
-            // a turn covers the 32 multiples of 64 in [r0, r0 + 2048): the leaves that own them lie inside [r0 - 63, r0 + 2047 + 128],
-            // so that stretch of points is staged in LDS by all threads (independent coalesced loads) and the groups sum from there
-            // the points of the NEXT turn are requested before the leaves of this turn are summed and only land in LDS after them
-            int2 nxt[9];
+            float* lsR = want_rev ? leafbuf_rev + (src.off[i] >> 6) + 2 * i : nullptr;
+            const int grp = tid >> 3, j = tid & 7;  // 32 groups of 8 lanes, one leaf per group, turn and direction
+            // A turn covers the 32 multiples of 64 in [r0, r0 + 2048).  The leaves of numpy's tree that own them lie inside
+            // [r0 - 63, r0 + 2047 + 128]; the leaves of the REVERSED sequence that own the multiples of 64 of the mirrored interval
+            // [ns - r0 - 2048, ns - r0) map to forward segments inside [r0 - 129, r0 + 2048 + 128).  So one stretch of points, staged
+            // in LDS by all threads (independent coalesced loads), serves both directions -- and the bounding box (a point is read once).
+            // The points of the NEXT turn are requested before the leaves of this turn are summed and only land in LDS after them.
+            constexpr int NX = (2048 + 2 * ORIP_PF_MARGIN + 255) / 256;
+            int2 nxt[NX];
             auto request = [&](int64_t r0) {
-                const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);
+                const int64_t lo = max((int64_t)0, r0 - ORIP_PF_MARGIN), hi = min(n, r0 + 2048 + ORIP_PF_MARGIN);
 #pragma unroll
-                for (int u = 0; u < 9; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2(q) : make_int2(0, 0); }
+                for (int u = 0; u < NX; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2(q) : make_int2(0, 0); }
             };
             request(0);
-            for (int64_t r0 = 0; r0 < ns; r0 += 32 * 64) {
-                const int64_t lo = max((int64_t)0, r0 - 64), hi = min(n, r0 + 2048 + 130);       // points [lo, hi)
+            for (int64_t r0 = 0; r0 < n; r0 += 32 * 64) {      // (the last turn may hold points only: the bounding box wants them all)
+                const int64_t lo = max((int64_t)0, r0 - ORIP_PF_MARGIN), hi = min(n, r0 + 2048 + ORIP_PF_MARGIN);       // points [lo, hi)
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 9; u++) if (lo + tid + 256 * u < hi) stage[tid + 256 * u] = nxt[u];
+                for (int u = 0; u < NX; u++) {
+                    const int64_t q = lo + tid + 256 * u;
+                    if (q < hi) {
+                        stage[tid + 256 * u] = nxt[u];
+                        if (q >= r0 && q < r0 + 2048) { x0 = min(x0, nxt[u].x); x1 = max(x1, nxt[u].x); y0 = min(y0, nxt[u].y); y1 = max(y1, nxt[u].y); }
+                    }
+                }
                 __syncthreads();
-                if (r0 + 32 * 64 < ns) request(r0 + 32 * 64);
+                if (r0 + 32 * 64 < n) request(r0 + 32 * 64);
+                const int32_t* sp = reinterpret_cast<const int32_t*>(stage) - 2 * lo;        // sp[2 * k] = x of point k
+                auto leaf_of = [&](int64_t pm, int64_t& s, int64_t& len) {                   // the leaf of numpy's tree over ns elements that holds element pm
+                    s = 0; len = ns;
+                    while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
+                };
                 const int64_t pm = r0 + (int64_t)grp * 64;
                 if (pm < ns) {
-                    int64_t s = 0, len = ns;
-                    while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
+                    int64_t s, len; leaf_of(pm, s, len);
                     if (((s + 63) >> 6) << 6 == pm) {   // every multiple of 64 lies in exactly one leaf; its first one owns the leaf
-                        const int32_t* sp = reinterpret_cast<const int32_t*>(stage) - 2 * lo;        // sp[2 * k] = x of point k
                         float v = (what & 1) ? pairwise_leaf_g8<0>(sp, s, len, j) : pairwise_leaf_g8<1>(sp, s, len, j);
                         if (j == 0) ls[pm >> 6] = v;
+                    }
+                }
+                if (want_rev) {
+                    // multiples of 64 of the reversed index space inside the mirrored interval [max(0, ns - r0 - 2048), ns - r0)
+                    const int64_t ilo = max((int64_t)0, ns - r0 - 2048), ihi = ns - r0;
+                    const int64_t pmr = (((ilo + 63) >> 6) << 6) + (int64_t)grp * 64;
+                    if (pmr < ihi) {
+                        int64_t s, len; leaf_of(pmr, s, len);
+                        if (((s + 63) >> 6) << 6 == pmr) {
+                            float v = pairwise_leaf_g8_rev(sp, ns, s, len, j);
+                            if (j == 0) lsR[pmr >> 6] = v;
+                        }
                     }
                 }
             }
@@ -231,38 +270,49 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                 }
                 return true;
             };
-            {
-                int64_t s, len;
-                if (node_of(ORIP_PW_DEPTH, tid, s, len)) part[(1 << ORIP_PW_DEPTH) + tid] = pairwise_subtree(ls, s, len, nullptr, 0);
-            }
-            for (int d = ORIP_PW_DEPTH - 1; d >= 0; d--) {
-                __syncthreads();
-                if (tid < (1 << d)) {
-                    int64_t s, len; const int code = (1 << d) + tid;
-                    if (node_of(d, tid, s, len)) part[code] = (len <= 128) ? ls[(s + 63) >> 6] : part[2 * code] + part[2 * code + 1];
+            for (int dir = 0; dir < (want_rev ? 2 : 1); dir++) {
+                const float* lsd = dir ? lsR : ls;
+                {
+                    int64_t s, len;
+                    if (node_of(ORIP_PW_DEPTH, tid, s, len)) part[(1 << ORIP_PW_DEPTH) + tid] = pairwise_subtree(lsd, s, len, nullptr, 0);
                 }
+                for (int d = ORIP_PW_DEPTH - 1; d >= 0; d--) {
+                    __syncthreads();
+                    if (tid < (1 << d)) {
+                        int64_t s, len; const int code = (1 << d) + tid;
+                        if (node_of(d, tid, s, len)) part[code] = (len <= 128) ? lsd[(s + 63) >> 6] : part[2 * code] + part[2 * code + 1];
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) { if (dir) perR = part[1]; else per = part[1]; }
+                __syncthreads();
             }
-            __syncthreads();
-            if (tid == 0) per = part[1];
         }
-        if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; }
+        rx0[tid] = x0; rx1[tid] = x1; ry0[tid] = y0; ry1[tid] = y1; rarc[tid] = arc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) { rx0[tid] = min(rx0[tid], rx0[tid + s]); rx1[tid] = max(rx1[tid], rx1[tid + s]); ry0[tid] = min(ry0[tid], ry0[tid + s]); ry1[tid] = max(ry1[tid], ry1[tid + s]); rarc[tid] += rarc[tid + s]; }
+            __syncthreads();
+        }
+        if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; if (want_rev) per_rev[i] = perR; }
         __syncthreads();
     }
 }
 // features of every polyline of a list: short ones one lane each, long ones one block each
 template <class Src>
-static int vfeatures_src(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat) {
+static int vfeatures_src(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev = nullptr) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_poly_features<Src>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src, n, what, feat);
+    if (!per_rev) what &= ~32;
+    hipLaunchKernelGGL(k_poly_features<Src>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src, n, what, feat, per_rev);
     if (total > ORIP_LONG_POLY) {
         const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
-        HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) + (size_t)n * 16 + 64));
-        float* leafbuf = LN(c).vtmp[11].as<float>();
-        unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
+        HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) * ((what & 32) ? 2 : 1) + (size_t)n * 16 + 64));
+        float* leafbuf = LN(c).vtmp[11].as<float>(); float* leafbuf_rev = (what & 32) ? leafbuf + nleaf : nullptr;
+        unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf * ((what & 32) ? 2 : 1)); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
         ProfScope ps(c, "k_poly_features_long");
-        hipLaunchKernelGGL(k_poly_features_long<Src>, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout);
+        hipLaunchKernelGGL(k_poly_features_long<Src>, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev);
     }
     HIPC(c, hipGetLastError());
     return 0;

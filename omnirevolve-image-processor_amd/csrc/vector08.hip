@@ -140,6 +140,98 @@ __global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, do
         if (lane == 0) { rs_finish(r, acc, n, step); info[i] = r; }
     }
 }
+// ---- both reading directions of every polyline in one launch (prefetch08): the reversed polyline has the same segment lengths in
+// reverse order, and its float32 running sum is a second, independent serial chain -- two chains interleave in one wavefront for the
+// price of one (a dependent add waits ~10 cycles for its predecessor anyway).  Forward = the polyline as split_small keeps it (opened
+// when closed); reversed = all its points backwards (stage 07 never flips a closed contour, so closed ones get no reversed entry).
+// cum / info of the reversed reading live `rev_off` floats / `n_polys` entries behind the forward ones.
+template <class Src>
+__global__ __launch_bounds__(128) void k_cumlen2(Src src, const PolyFeat* __restrict__ feat07, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_polys) return;
+    auto cu = src.cur(i); const int64_t nfull = src.len(i);
+    const bool closed = feat07[i].closed != 0;
+    for (int dir = 0; dir < 2; dir++) {
+        int64_t n = (dir == 0 && closed && nfull > 0) ? nfull - 1 : nfull;         // the view: opened forward, whole reversed
+        float* s = cum + (dir ? rev_off : 0) + src.off[i];
+        auto P = [&](int64_t k) { return dir ? cu.at(nfull - 1 - k) : cu.at(k); };
+        RsInfo r; r.n_eff = n; r.total = 0; r.m = 0; r.pass = 0;
+        if (dir == 1 && closed) { r.n_eff = 0; info[n_polys + i] = r; continue; }
+        const int2 pf = P(0);
+        auto same_as_first = [&](int64_t k) { const int2 q = P(k); return q.x == pf.x && q.y == pf.y; };
+        if (n >= 2 && same_as_first(n - 1)) n -= 1;         // _ensure_open inside _virtual_draw (08:127)
+        r.n_eff = n;
+        if (n >= 2) {
+            if (n > 2 && same_as_first(n - 1)) n -= 1;    // _is_closed inside _resample_arclen (08:56)
+            r.n_eff = n;
+            if (n <= ORIP_LONG_CUM) {
+                float acc = 0.f; s[0] = 0.f;
+                int2 a = P(0);
+                for (int64_t k = 0; k + 1 < n; k++) {
+                    const int2 b = P(k + 1);
+                    float dx = (float)b.x - (float)a.x, dy = (float)b.y - (float)a.y; float qx = dx * dx, qy = dy * dy; const float sl = sqrtf(qx + qy);
+                    acc = (k == 0) ? sl : acc + sl; s[k + 1] = acc; a = b;
+                }
+                rs_finish(r, acc, n, step);
+            }
+        }
+        info[dir ? n_polys + i : i] = r;
+    }
+}
+template <class Src>
+__global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
+    const int lane = threadIdx.x;
+    for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
+        const int64_t i = ord[rr];
+        RsInfo rf = info[i], rb = info[n_polys + i];
+        const bool do_f = rf.n_eff > ORIP_LONG_CUM, do_b = rb.n_eff > ORIP_LONG_CUM;
+        if (!do_f && !do_b) continue;
+        auto cu = src.cur(i); const int64_t nfull = src.len(i);
+        float* sf = cum + src.off[i]; float* sb = cum + rev_off + src.off[i];
+        const int64_t nsf = do_f ? rf.n_eff - 1 : 0, nsb = do_b ? rb.n_eff - 1 : 0, nsm = nsf > nsb ? nsf : nsb;
+        float accf = 0.f, accb = 0.f;
+        if (lane == 0) { if (do_f) sf[0] = 0.f; if (do_b) sb[0] = 0.f; }
+        // per turn: 4 windows of 64 segment lengths in each direction; the points of the next turn are requested before this turn's chains run
+        auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4], int2 (&c2)[4], int2 (&d2)[4]) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int64_t k = base + 64 * w + lane;
+                const bool inf = k < nsf, inb = k < nsb;
+                a[w] = inf ? cu.at(k) : make_int2(0, 0); b2[w] = inf ? cu.at(k + 1) : make_int2(0, 0);
+                c2[w] = inb ? cu.at(nfull - 1 - k) : make_int2(0, 0); d2[w] = inb ? cu.at(nfull - 2 - k) : make_int2(0, 0);
+            }
+        };
+        auto lengths = [&](const int2 (&a)[4], const int2 (&b2)[4], float (&sl)[4]) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) { float dx = (float)b2[w].x - (float)a[w].x, dy = (float)b2[w].y - (float)a[w].y; float qx = dx * dx, qy = dy * dy; sl[w] = sqrtf(qx + qy); }
+        };
+        int2 ra[4], rb2[4], rc[4], rd[4]; float curf[4], curb[4];
+        request(0, ra, rb2, rc, rd); lengths(ra, rb2, curf); lengths(rc, rd, curb);
+        for (int64_t base = 0; base < nsm; base += 256) {
+            request(base + 256, ra, rb2, rc, rd);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int64_t k = base + 64 * w + lane;
+                float df = (lane == 0) ? __fadd_rn(accf, curf[w]) : curf[w], db = (lane == 0) ? __fadd_rn(accb, curb[w]) : curb[w];
+                float pf_ = df, pb_ = db;
+#pragma unroll
+                for (int j = 1; j < 64; j++) {
+                    pf_ = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pf_), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), df);
+                    pb_ = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pb_), 0x138, 0xf, 0xf, true)), db);
+                }
+                accf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_), 63));
+                accb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pb_), 63));
+                if (k < nsf) sf[k + 1] = pf_;
+                if (k < nsb) sb[k + 1] = pb_;
+            }
+            lengths(ra, rb2, curf); lengths(rc, rd, curb);
+        }
+        if (lane == 0) {
+            if (do_f) { rs_finish(rf, accf, rf.n_eff, step); info[i] = rf; }
+            if (do_b) { rs_finish(rb, accb, rb.n_eff, step); info[n_polys + i] = rb; }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_rank_counts(const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t n, unsigned* __restrict__ mr) {
     int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r < n) mr[r] = info[ord[r]].m;
@@ -1070,9 +1162,13 @@ __global__ __launch_bounds__(256) void k_pf_views(const PolyFeat* __restrict__ f
     VView b; b.wid = (unsigned)i; b.first = 0u; b.len = len; b.rev = 1u;
     vf[i] = a; vr[i] = b; lf[i] = a.len; lr[i] = b.len;
 }
-__global__ __launch_bounds__(256) void k_pf_pick_feat(const VView* __restrict__ sview, int64_t n, const PolyFeat* __restrict__ pf, int64_t npf, PolyFeat* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_pf_pick_feat(const VView* __restrict__ sview, int64_t n, const PolyFeat* __restrict__ pf, const float* __restrict__ per_rev, PolyFeat* __restrict__ out) {
     int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < n) { const VView v = sview[k]; out[k] = pf[v.rev ? npf + (int64_t)v.wid : (int64_t)v.wid]; }
+    if (k >= n) return;
+    const VView v = sview[k];
+    PolyFeat f = pf[v.wid];
+    if (v.rev) { const int32_t ax = f.sx, ay = f.sy; f.sx = f.ex; f.sy = f.ey; f.ex = ax; f.ey = ay; f.per = per_rev[v.wid]; }      // the reversed polyline: same box, same points, ends swapped, its own pairwise sum
+    out[k] = f;
 }
 __global__ __launch_bounds__(256) void k_pf_pick_info(const VView* __restrict__ kview, int64_t nk, const RsInfo* __restrict__ pinfo, int64_t npf, const int64_t* __restrict__ off_f,
                                                        const int64_t* __restrict__ off_r, int64_t tot_f, RsInfo* __restrict__ info, int64_t* __restrict__ cumoff) {
@@ -1080,7 +1176,7 @@ __global__ __launch_bounds__(256) void k_pf_pick_info(const VView* __restrict__ 
     if (j >= nk) return;
     const VView v = kview[j];
     info[j] = pinfo[v.rev ? npf + (int64_t)v.wid : (int64_t)v.wid];
-    cumoff[j] = v.rev ? tot_f + off_r[v.wid] : off_f[v.wid];
+    cumoff[j] = v.rev ? tot_f + off_r[v.wid] : off_f[v.wid];       // (both readings of a polyline sit at its offset in the scaled list)
 }
 struct StreamSwap {       // everything issued while this lives goes to the lane's side stream
     LaneRes& l;
@@ -1094,40 +1190,27 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
     const int64_t n = S.n, total = S.total;
     if (n <= 0 || total <= 0 || total > 0x3fffffff) return 0;
     const double step = std::max(1.0, P.sample_step);
-    HIPC(c, F.feat.ensure((size_t)2 * n * sizeof(PolyFeat) + 64));
+    HIPC(c, F.feat.ensure((size_t)n * (sizeof(PolyFeat) + 4) + 64));
     HIPC(c, F.info.ensure((size_t)2 * n * sizeof(RsInfo) + 64));
     HIPC(c, F.cum.ensure((size_t)2 * total * 4 + 64));
     HIPC(c, F.ord.ensure((size_t)n * 16 + 64));
-    for (DPolys* L : {&F.fwd_open, &F.rev}) {
-        L->n = n; L->total = total; L->virt = true; L->pts_ok = false; L->vident = false; L->vlayer = S.vlayer; L->vepoch = S.vepoch; L->scaled = S.scaled; L->vsepoch = S.vsepoch; L->pf_tag = 0;
-        HIPC(c, L->off.ensure((size_t)(n + 1) * 8 + 64)); HIPC(c, L->vview.ensure((size_t)n * sizeof(VView) + 64));
-    }
-    HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 16 + 64));
     {
         StreamSwap sw(LN(c));                       // LN(c).stream is the side stream from here to the end of the block
-        int64_t* lf = LN(c).tmpE.as<int64_t>(); int64_t* lr = lf + (n + 1);
-        hipLaunchKernelGGL(k_pf_views, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, feat07, S.off.as<int64_t>(), n, F.fwd_open.vview.as<VView>(), F.rev.vview.as<VView>(), lf, lr);
-        ORIP_TRY(vscan_excl<int64_t>(c, lf, F.fwd_open.off.as<int64_t>(), (size_t)n + 1));
-        ORIP_TRY(vscan_excl<int64_t>(c, lr, F.rev.off.as<int64_t>(), (size_t)n + 1));
-        PolyFeat* ff = F.feat.as<PolyFeat>(); RsInfo* inf = F.info.as<RsInfo>(); float* cum = F.cum.as<float>();
-        VSrc sS, sF, sR; ORIP_TRY(vsrc_of(c, S, sS)); ORIP_TRY(vsrc_of(c, F.fwd_open, sF)); ORIP_TRY(vsrc_of(c, F.rev, sR));
-        // A0 / A1: features of the opened polyline in both directions (the forward ones over the scaled list itself, as split_small does)
-        ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16, ff));
-        ORIP_TRY(vfeatures_src(c, sR, n, total, 1 | 16, ff + n));
-        // A2: cumulative lengths; long polylines longest first
+        PolyFeat* ff = F.feat.as<PolyFeat>(); float* per_rev = reinterpret_cast<float*>(ff + n); RsInfo* inf = F.info.as<RsInfo>(); float* cum = F.cum.as<float>();
+        VSrc sS; ORIP_TRY(vsrc_of(c, S, sS));
+        // A2 first (the long serial chains): cumulative lengths of both readings; long polylines longest first
         unsigned* kin = F.ord.as<unsigned>(); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* ordl = vin + n;
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
-        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sF, n, step, cum, inf);
-                                        hipLaunchKernelGGL(k_cumlen<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sR, n, step, cum + total, inf + n); }
-        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long");
-            hipLaunchKernelGGL(k_cumlen_long<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sF, n, step, cum, inf, ordl);
-            hipLaunchKernelGGL(k_cumlen_long<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sR, n, step, cum + total, inf + n, ordl); }
+        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long2<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
+        // A0 / A1: bounding box and numpy perimeter of the opened polyline, read forwards and backwards, in one pass over the points
+        ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16 | 32, ff, per_rev));
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream));
     }
     HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));      // the main stream (behind the greedy kernel) goes on when both are done
-    F.valid = true; F.tag = g_pf_tag.fetch_add(1); F.n = n; F.tot_f = total; F.step = step;
+    F.valid = true; F.tag = g_pf_tag.fetch_add(1); F.n = n; F.tot_f = total; F.step = step; F.src_off = S.off.as<int64_t>();
     return 0;
 }
 
@@ -1151,7 +1234,7 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     if (is_coded(src) && P.tap_max_v > 64) ORIP_TRY(orip_polys_materialize(c, src));      // the walk-coded tap test copies <= 64 vertices (default tap_max_vertices: 50)
     const LaneRes::Prefetch08& F = LN(c).pf08;
     if (kept_feat && is_coded(src) && src.pf_tag && F.valid && F.tag == src.pf_tag && !src.vident)        // computed under stage 07's greedy, per walk and direction
-        hipLaunchKernelGGL(k_pf_pick_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.vview.as<VView>(), n, F.feat.as<PolyFeat>(), F.n, sfeat);
+        hipLaunchKernelGGL(k_pf_pick_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.vview.as<VView>(), n, F.feat.as<PolyFeat>(), reinterpret_cast<const float*>(F.feat.as<PolyFeat>() + F.n), sfeat);
     else ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat));
     { ProfScope ps(c, "k_split_small08"); ORIP_WITH_SRC(c, src, sv, { hipLaunchKernelGGL(k_split_small08<decltype(sv)>, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, sv, n, P, sfeat, is_tap, is_keep, tap_xy, kd); }); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
@@ -1232,7 +1315,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         int64_t* cumoff = LN(c).vtmp[1].as<int64_t>(); float* cum = reinterpret_cast<float*>(cumoff + (nk + 2));
         if (picked) {       // cumulative lengths and sample counts were taken under stage 07's greedy, per walk and direction: pick this list's
             cum = F.cum.as<float>();
-            hipLaunchKernelGGL(k_pf_pick_info, dim3(cdiv(nk, 256)), dim3(256), 0, LN(c).stream, kept0.p.vview.as<VView>(), nk, F.info.as<RsInfo>(), F.n, F.fwd_open.off.as<int64_t>(), F.rev.off.as<int64_t>(), F.tot_f, info, cumoff);
+            hipLaunchKernelGGL(k_pf_pick_info, dim3(cdiv(nk, 256)), dim3(256), 0, LN(c).stream, kept0.p.vview.as<VView>(), nk, F.info.as<RsInfo>(), F.n, F.src_off, F.src_off, F.tot_f, info, cumoff);
         } else {
         HIPC(c, hipMemcpyAsync(cumoff, kept0.p.off.p, (size_t)(nk + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
