@@ -38,7 +38,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->lab_tabs};
+    DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->lab_tabs, &c->cref, &c->cpix};
     for (DBuf* b : bufs) b->release();
     for (auto& l : c->ln) {
         l.tmpE.release(); l.tmpF.release(); l.flags.release(); l.canvas.release();

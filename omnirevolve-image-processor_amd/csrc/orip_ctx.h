@@ -147,6 +147,7 @@ struct orip_ctx {
     DBuf edges;     // u8 [K,H,W]
     DBuf skel;      // u8 [K,H,W]
     DBuf tmpA, tmpB, tmpC, tmpD;   // raster scratch
+    DBuf cref, cpix;               // forced stretches of the skeletons (walker.h: ST_CHAIN): position plane and chain pixel lists
     DBuf lab_tabs;  // u16 gamma[256] + u16 cbrt[3072] + i32 coeffs[9]
     bool tabs_ready = false;
     const void* edge_bits = nullptr;   // bit planes of `edges` left in lane 0's scratch by stage 03 (nullptr: not available); consumed by stage 04

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_skel_state(const u8* __restrict__ skel,
                 int yy = y + dy, xx = x + dx;
                 if (yy >= 0 && yy < H && xx >= 0 && xx < W && s[(size_t)yy * W + xx]) deg++;
             }
-        v = ST_FG | (deg == 1 ? ST_END : 0) | (deg >= 3 ? ST_JUN : 0);
+        v = ST_FG | (deg == 1 ? ST_END : 0) | (deg >= 3 ? ST_JUN : 0) | (deg == 2 ? ST_DEG2 : 0);
     }
     d[o] = v;
 }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
     const unsigned long long* s = bits + nw * blockIdx.z;
     u8* sk = skel + (size_t)H * W * blockIdx.z; u8* so = st + (size_t)H * W * blockIdx.z;
     const int lane = threadIdx.x & 63;
-    unsigned long long fg = 0, en = 0, ju = 0;
+    unsigned long long fg = 0, en = 0, ju = 0, d2 = 0;
     if (w0 + lane < nw) {
         const size_t wi = w0 + lane;
         fg = s[wi];
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
             unsigned long long b0, b1, b2, b3; count8(n, b0, b1, b2, b3);
             en = fg & b0 & ~b1 & ~b2 & ~b3;                   // exactly one neighbour
             ju = fg & (b2 | b3 | (b1 & b0));                  // three or more
+            d2 = fg & ~b0 & b1 & ~b2 & ~b3;                   // exactly two: a walk passing through has no choice (walker.h: forced stretches)
         }
     }
     auto bc = [&](unsigned long long v, int j) -> unsigned long long {
@@ -292,13 +293,79 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
     };
     for (int j = 0; j < 64; j++) {
         const size_t wi = w0 + j; if (wi >= nw) break;
-        const unsigned long long f = bc(fg, j), e = bc(en, j), q = bc(ju, j);
+        const unsigned long long f = bc(fg, j), e = bc(en, j), q = bc(ju, j), t2 = bc(d2, j);
         const int y = (int)(wi / Ww), x = (int)(wi % Ww) * 64 + lane;
         if (x < W) {
             const bool on = (f >> lane) & 1ULL;
             sk[(size_t)y * W + x] = on ? 255 : 0;
-            so[(size_t)y * W + x] = on ? (u8)(ST_FG | (((e >> lane) & 1ULL) ? ST_END : 0) | (((q >> lane) & 1ULL) ? ST_JUN : 0)) : (u8)0;
+            so[(size_t)y * W + x] = on ? (u8)(ST_FG | (((e >> lane) & 1ULL) ? ST_END : 0) | (((q >> lane) & 1ULL) ? ST_JUN : 0) | (((t2 >> lane) & 1ULL) ? ST_DEG2 : 0)) : (u8)0;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forced stretches (walker.h: ST_CHAIN): maximal chains of degree-2 skeleton pixels, listed when at least ORIP_CHAIN_MIN long.
+//   k_chain_ends : a degree-2 pixel with a neighbour that is not degree-2 ends a chain
+//   k_chain_build: one thread per end pixel walks its chain (each pixel has exactly one way on); the end with the smaller pixel index
+//                  owns the chain, takes room in cpix with one atomic, walks it again and writes cpix / cref / the state flags
+// Runs on lane 0's side stream underneath the component labelling; the traces wait for it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_ends(const u8* __restrict__ st, int H, int W, int64_t n, unsigned* __restrict__ ends, unsigned* __restrict__ n_ends, unsigned cap) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    uint32_t w4 = 0;
+    if (i4 + 3 < n) w4 = *reinterpret_cast<const uint32_t*>(st + i4); else for (int j = 0; j < 4 && i4 + j < n; j++) w4 |= (uint32_t)st[i4 + j] << (8 * j);
+    if (!(w4 & 0x04040404u)) return;
+    const int64_t plane = (int64_t)H * W;
+    for (int j = 0; j < 4; j++) {
+        if (!((w4 >> (8 * j)) & ST_DEG2)) continue;
+        const int64_t g = i4 + j; const int layer = (int)(g / plane); const int64_t p = g - (int64_t)layer * plane;
+        const int y = (int)(p / W), x = (int)(p % W);
+        const u8* s = st + plane * layer;
+        bool end = false;
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            if (!dy && !dx) continue;
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const u8 v = s[(size_t)yy * W + xx];
+            if ((v & ST_FG) && !(v & ST_DEG2)) end = true;
+        }
+        if (end) { const unsigned k = atomicAdd(n_ends, 1u); if (k < cap) ends[k] = ((unsigned)layer << 26) | (unsigned)p; }
+    }
+}
+__global__ __launch_bounds__(64) void k_chain_build(u8* __restrict__ st, int H, int W, const unsigned* __restrict__ ends, const unsigned* __restrict__ n_ends, unsigned cap_ends,
+                                                     unsigned* __restrict__ cpix, unsigned* __restrict__ cref, unsigned* __restrict__ n_cpix, unsigned cap_cpix) {
+    const unsigned ne = min(*n_ends, cap_ends);
+    const unsigned e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= ne) return;
+    const int layer = (int)(ends[e] >> 26); const unsigned p0 = ends[e] & 0x3ffffffu;
+    const int64_t plane = (int64_t)H * W;
+    u8* s = st + plane * layer; unsigned* cr = cref + plane * layer;
+    // the way on from `cur` (a degree-2 pixel): its degree-2 neighbour that is not `prev`; ~0u: the chain ends here
+    auto next_of = [&](unsigned cur, unsigned prev) -> unsigned {
+        const int y = (int)(cur / (unsigned)W), x = (int)(cur % (unsigned)W);
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            if (!dy && !dx) continue;
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const unsigned q = (unsigned)yy * (unsigned)W + (unsigned)xx;
+            if (q == prev) continue;
+            const u8 v = s[q];
+            if ((v & ST_FG) && (v & ST_DEG2)) return q;
+        }
+        return ~0u;
+    };
+    unsigned m = 1, cur = p0, prev = ~0u;
+    for (;;) { const unsigned nx = next_of(cur, prev); if (nx == ~0u || m > (1u << 24)) break; prev = cur; cur = nx; m++; }
+    if (m < ORIP_CHAIN_MIN || !(p0 < cur)) return;                   // short, or the other end owns it
+    const unsigned base = atomicAdd(n_cpix, m + 2u);
+    if (base + m + 2u > cap_cpix) return;
+    cpix[base] = ORIP_CHAIN_SENTINEL; cpix[base + m + 1u] = ORIP_CHAIN_SENTINEL;
+    cur = p0; prev = ~0u;
+    for (unsigned j = 0; j < m; j++) {
+        cpix[base + 1u + j] = cur; cr[cur] = base + 1u + j;
+        s[cur] = (u8)(s[cur] | ST_CHAIN | ((j == 0 || j == m - 1u) ? ST_CHAIN_END : 0));
+        const unsigned nx = next_of(cur, prev); prev = cur; cur = nx;
     }
 }
 
@@ -313,6 +380,7 @@ struct Prep04 {
     unsigned F[ORIP_MAX_LAYERS];                    // log capacity factor of the trace in flight
     bool launched[ORIP_MAX_LAYERS];
     bool memo_clear[ORIP_MAX_LAYERS];               // the layer's memo plane was zeroed on its lane while the raster part ran
+    bool chains = false;                            // forced stretches are listed (cref / cpix) and flagged in the state plane
 };
 void orip_contours_free(orip_ctx* c) { delete static_cast<Prep04*>(c->prep04); c->prep04 = nullptr; }
 
@@ -438,6 +506,22 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     }
     R.M = M; R.NC = 0;
     if (M == 0) { HIPC(c, hipStreamSynchronize(LN(c).stream)); R.ready = true; return 0; }
+    // ---- forced stretches (walker.h: ST_CHAIN), on the side stream underneath the component work below; the traces wait for ev3
+    R.chains = !getenv("ORIP_NO_CHAINS");
+    if (R.chains) {
+        const unsigned cap_ends = M, cap_cpix = 2u * M + 256u;
+        HIPC(c, c->cref.ensure(plane * (size_t)K * 4 + 64));
+        HIPC(c, c->cpix.ensure((size_t)cap_cpix * 4 + (size_t)cap_ends * 4 + 64));
+        unsigned* cpix = c->cpix.as<unsigned>(); unsigned* ends = cpix + cap_cpix;
+        unsigned* d_cn = LN(c).flags.as<unsigned>() + 232;                          // {ends, cpix entries}
+        hipStream_t s2 = LN(c).stream2;
+        HIPC(c, hipMemsetAsync(cpix, 0xff, (size_t)cap_cpix * 4, s2));             // sentinels everywhere, 64 of them in front of the first chain
+        const unsigned init[2] = {0u, 64u};
+        HIPC(c, hipMemcpyAsync(d_cn, init, 8, hipMemcpyHostToDevice, s2));
+        hipLaunchKernelGGL(k_chain_ends, dim3(cdiv(cdiv(n, 4), 256)), block, 0, s2, c->tmpC.as<u8>(), H, W, n, ends, d_cn, cap_ends);
+        hipLaunchKernelGGL(k_chain_build, dim3(cdiv(cap_ends, 64)), dim3(64), 0, s2, c->tmpC.as<u8>(), H, W, ends, d_cn, cap_ends, cpix, c->cref.as<unsigned>(), d_cn + 1, cap_cpix - 64u);
+        HIPC(c, hipEventRecord(LN(c).ev3, s2));
+    }
     // keys / lin (double buffers for the sort)
     HIPC(c, LN(c).vtmp[0].ensure((size_t)M * 4 * 4 + 64));
     unsigned* keys_in = LN(c).vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
@@ -469,6 +553,7 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     HIPC(c, LN(c).vtmp[3].ensure((size_t)NC * 4 + 64));
     WalkArgs& A = R.A; memset(&A, 0, sizeof(A));
     A.H = H; A.W = W; A.plane = (int64_t)plane; A.st = c->tmpC.as<u8>(); A.keys = keys; A.lin = lin; A.comp_start = comp_start; A.nc = NC;
+    if (R.chains) { A.cref = c->cref.as<unsigned>(); A.cpix = c->cpix.as<unsigned>(); }
     hipLaunchKernelGGL(k_gather_head_layers, dim3(cdiv(NC, 256)), block, 0, LN(c).stream, keys, comp_start, NC, LN(c).vtmp[3].as<unsigned>());
     HIPC(c, hipMemcpyAsync(h_keyfirst.data(), LN(c).vtmp[3].p, (size_t)NC * 4, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
@@ -520,6 +605,7 @@ static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F) {
     A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)F * b0 + (size_t)256 * c0);
     A.cap_factor = F; A.comp_order = R.order + c0; A.nc = NCl;
     int* d_over = LN(c).flags.as<int>() + 20; A.overflow = d_over;
+    if (R.chains) HIPC(c, hipStreamWaitEvent(LN(c).stream, c->ln[0].ev3, 0));            // the chain lists and flags (orip_contours_prepare, side stream)
     if (!R.memo_clear[layer]) HIPC(c, hipMemsetAsync(A.memo + plane * 8 * layer, 0, plane * 8 * 4, LN(c).stream));
     R.memo_clear[layer] = false;                     // a retry (or a second trace without prepare) clears it itself
     HIPC(c, hipMemsetAsync(A.winfo + 2 * (size_t)b0, 0, (size_t)2 * Ml * sizeof(WalkInfo), LN(c).stream));
@@ -558,8 +644,8 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
         for (size_t i = 0; i < h.size(); i++) tot[i % 16] += h[i];
         for (size_t i = 0; i < NCl; i++) if (h[i * 16 + 7] > h[big * 16 + 7]) big = i;
         const unsigned long long* d = &h[big * 16];
-        fprintf(stderr, "[walk dbg] layer %d NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu | largest fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu\n",
-                layer, NCl, Ml, R.F[layer], tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
+        fprintf(stderr, "[walk dbg] layer %d NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu | largest fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu jumped=%llu\n",
+                layer, NCl, Ml, R.F[layer], tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[15]);
         if (d[8]) fprintf(stderr, "[walk prof] layer %d largest component: cycles total=%llu window loads=%llu scans=%llu look-ups=%llu | look-ups=%llu loop exits=%llu\n",
                           layer, d[8], d[9], d[10], d[11], d[12], d[13]);
         if (d[8]) fprintf(stderr, "[walk prof]   inside the look-ups: duplicate check %llu cycles\n", d[14]);

@@ -34,6 +34,19 @@ typedef uint8_t u8;
 #define ST_VIS 0x40
 #define ST_JUN 2
 #define ST_END 1
+// Forced stretches.  A skeleton pixel with exactly two neighbours leaves a walk that arrives from one of them no choice (04:150,180:
+// the only neighbour that is not `prev`), whatever has been visited.  raster04.hip lists the maximal chains of such pixels that are at
+// least ORIP_CHAIN_MIN long (cpix: their pixel indices in chain order, a sentinel on either side; cref: the position of a chain pixel in
+// cpix) and flags them in the state plane: ST_CHAIN on every pixel of a listed chain, ST_CHAIN_END (the window's "stop here" bit) on its
+// two end pixels.  A leftover walk that steps onto an end pixel leaves the stepping loop there and takes the stretch ahead in one go
+// (trace_component: chain_jump): 64 pixels per round instead of one step per ~350 cycles.
+#define ST_DEG2 0x04
+#define ST_CHAIN 0x08
+#define ST_CHAIN_END 0x10
+#define ORIP_CHAIN_SENTINEL 0xffffffffu
+#ifndef ORIP_CHAIN_MIN
+#define ORIP_CHAIN_MIN 24
+#endif
 
 struct WalkInfo {            // one per potential walk: slot 2b+(q-b) for the endpoint walk starting at list index q, 2b+fg+(q-b) for a phase-2 walk
     unsigned len_kept;       // total points if the path is kept (>= 5 points, 04:224), else 0
@@ -59,6 +72,8 @@ struct WalkArgs {
     WalkInfo* winfo;                   // [2*M]
     int* overflow;                     // set when a region was too small (host retries with a larger cap_factor)
     unsigned* log_used;                // optional: state-log entries of component c in use when its trace ended (the walk-coded lists read their pixels)
+    const unsigned* cref;              // optional, [K,H,W]: position of a chain pixel in cpix (only read where the state byte carries ST_CHAIN)
+    const unsigned* cpix;              // chain pixels (index inside their layer's plane), chain by chain, ORIP_CHAIN_SENTINEL before and after each
     // write pass
     const unsigned long long* pts_off; const unsigned* path_off;   // exclusive scans over winfo (len_kept, kept)
     unsigned long long layer_pts_base[ORIP_MAX_LAYERS]; unsigned layer_path_base[ORIP_MAX_LAYERS];
@@ -292,17 +307,28 @@ struct Wave {
         reload = (vk & WB_RING) != 0;
         return (u8)((vk & (ST_FG | ST_VIS | ST_END | ST_JUN)) | (fresh ? ST_VIS : 0));
     }
-    // after EV_DEAD: 2 = the cursor stands on the start pixel of the walk, 1 = it stood on the window ring (window re-placed), 0 = neither
+    // after EV_DEAD: 2 = the cursor stands on the start pixel of the walk, 1 = it stood on the window ring (window re-placed), 0 = neither,
+    // 3 = it stands on the end pixel of a listed chain (ST_CHAIN_END shares the window's "stop here" bit with the start-pixel flag): the
+    // caller jumps or calls unflag_cursor()
     __device__ int resume_flagged(unsigned steps) {
         const u8 cell = tile[li];
         if (cell & WB_HOME) {
             if (pl == home) return 2;
+            if (cell & ST_CHAIN) return 3;
             if (lane == 0) tile[li] = (u8)(cell & ~WB_HOME);          // the start pixel of an earlier walk: the flag is stale
             fence();
             if (!(cell & WB_RING)) return 1;
         }
         if (cell & WB_RING) { reload = true; place(steps); return 1; }
         return 0;
+    }
+    // the stepping loop may pass the flagged cell the cursor stands on (this window only: a reloaded window carries the flag again)
+    __device__ void unflag_cursor(unsigned steps) {
+        if (reload) place(steps);
+        const u8 cell = tile[li];
+        if (lane == 0) tile[li] = (u8)(cell & ~WB_HOME);
+        fence();
+        if (cell & WB_RING) { reload = true; place(steps); if (lane == 0) tile[li] = (u8)(tile[li] & ~WB_HOME); fence(); }
     }
     __device__ void log_code(u8*, unsigned, unsigned, int) {}      // the record of the step carries its code
     __device__ unsigned bcast(unsigned x, int src) const { return (unsigned)__shfl((int)x, src, 64); }
@@ -573,7 +599,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     const unsigned step_base = F * b + 256u * c, step_cap = F * fg + 256u;
     unsigned logcur = 0, stepcur = 0;
     bool over = false, stalled = false;
-    unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0;
+    unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0, d_jump = 0;
     unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0, t_f3 = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
         if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
@@ -644,13 +670,14 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
                 nofresh = 0;
             }
         };
-        // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow
-        auto flush_ = [&]() -> int {
+        // 0: nothing known, pending states committed; 1: the walk ended in a jump; 2: log overflow.
+        // ext: the pending states are not the records of the last h.nb steps but come from the caller, lane j holding the j-th (chain_jump)
+        auto flush_ = [&](bool ext, unsigned ext_state) -> int {
             const unsigned nb = h.nb - drop;
             if (!nb) { h.nb = 0; return 0; }
             const unsigned steps_b = h.steps - h.nb;                  // steps before the first pending state
             if (steps_b > flush_mark) { discard_run(); h.nbatch = nbatch0; }      // a fresh pixel since the last look-up: a new run
-            const unsigned myS = wv.pending(steps_b);                 // lane j: j-th pending state
+            const unsigned myS = ext ? ext_state : wv.pending(steps_b);           // lane j: j-th pending state
             const unsigned run_begin = log_base + logcur;
             const unsigned me = wv.l0();
             const bool act = me < nb;
@@ -686,9 +713,89 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             h.nb = 0;
             return 1;
         };
-        auto flush = [&]() -> int { const unsigned long long t_0 = WPROF_NOW(); n_flush++; const int r = flush_(); WPROF_ADD(t_flush, t_0); return r; };
+        auto flush = [&]() -> int { const unsigned long long t_0 = WPROF_NOW(); n_flush++; const int r = flush_(false, 0u); WPROF_ADD(t_flush, t_0); return r; };
         int ended = 0;
         unsigned stall = 0, stall_steps = ~0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // The cursor stands on the end pixel of a listed chain (it has just stepped onto it).  The pixels ahead along the chain are forced
+        // steps: taken 64 per round by the lanes -- as long as they are all fresh or all visited (the run is cut where that changes, and
+        // before the walk's start pixel), in the reference's order of events: pending no-fresh states are looked up before a fresh pixel is
+        // taken (EV_PEND), no-fresh steps are looked up state by state (the first known one ends the walk there), fresh pixels are marked.
+        // Leaves the cursor on the last pixel taken; the window is re-placed from the state plane.  Returns `ended` (0: walk goes on).
+        unsigned last_jump_end = ~0u;
+        auto chain_jump = [&]() -> int {
+            if (!A.cref || wv.pl == last_jump_end || wv.lastk >= 8) { wv.unflag_cursor(h.steps); return 0; }
+            const unsigned lane = wv.l0();
+            wv.flush_codes(slog, room, h.steps);                          // the records of the steps so far leave the wave: codes, and the visited
+            wv.fence();                                                   // marks the state bytes read below must already show
+            int res = 0; bool moved = false;
+            unsigned idx = wv.ld0(A.cref + (size_t)A.plane * layer + wv.pl);
+            // the chain on both sides of the cursor in one round trip: lane j reads the pixel j + 1 places up and j + 1 places down
+            unsigned q_up = A.cpix[idx + lane + 1u], q_dn = A.cpix[idx - lane - 1u];
+            // direction along the chain: away from where the walk came from (its neighbour in the chain, or a pixel outside the chain)
+            const unsigned prev_px = (unsigned)((int)wv.pl - (nby(wv.lastk) * W + nbx(wv.lastk)));
+            const unsigned c_m = wv.bcast(q_dn, 0), c_p = wv.bcast(q_up, 0);
+            int dir;
+            if (c_p == prev_px) dir = -1; else if (c_m == prev_px) dir = 1;                 // inside the chain: keep going
+            else dir = c_m == ORIP_CHAIN_SENTINEL ? 1 : -1;                                  // entered from outside at an end pixel: inwards
+            bool first_round = true;
+            while (true) {
+                const long long room_left = (long long)(room < g2 ? room : g2) - 80ll - (long long)h.steps;       // stay clear of the guard and of the end of the step log
+                if (room_left < 8) break;
+                const unsigned q = first_round ? (dir > 0 ? q_up : q_dn) : A.cpix[(unsigned)((int)idx + dir * (int)(lane + 1u))];      // the next 64 chain pixels (lanes past the sentinel read the neighbouring chain: masked)
+                first_round = false;
+                const int sent = wv.first(q == ORIP_CHAIN_SENTINEL);
+                const bool valid = sent < 0 || (int)lane < sent;
+                u8 sb = 0; if (valid) sb = wv.ld_state(q);
+                const bool fr = !(sb & ST_VIS);
+                const bool fr0 = wv.bcast(fr ? 1u : 0u, 0) != 0u;
+                const bool stop = !valid || fr != fr0 || q == wv.home;
+                int r = wv.first(stop); if (r < 0) r = 64;
+                bool go_on = r == 64 || wv.bcast((valid && q != wv.home) ? 1u : 0u, r < 64 ? r : 0) != 0u;      // cut by a change of freshness only: another round
+                if ((long long)r > room_left) { r = (int)room_left; go_on = false; }
+                if (r < (moved ? 1 : 8)) break;                                   // not worth leaving the stepping loop for
+                // direction code of step j: from the pixel before (lane j - 1's, or the cursor) to q
+                unsigned qp = (unsigned)__shfl_up((int)q, 1, 64); if (lane == 0) qp = wv.pl;
+                const int dd = (int)q - (int)qp; const int dy = dd > 1 ? 1 : (dd < -1 ? -1 : 0); const int dx = dd - dy * W;
+                const int kk = (dy + 1) * 3 + (dx + 1); const int k = kk > 4 ? kk - 1 : kk;
+                const unsigned myst = (q << 3) | (unsigned)k;
+                const unsigned nbp = h.nb;
+                if (!fr0 && nbp + (unsigned)r <= wv.nl()) {
+                    // the states still pending and the stretch's own are consecutive no-fresh states of the walk: one look-up for all of them
+                    const unsigned pend = nbp ? wv.pending(h.steps - nbp) : 0u;
+                    const unsigned ext = (unsigned)__shfl((int)myst, (int)((lane - nbp) & 63u), 64);
+                    if ((int)lane < r && h.steps + lane < room) slog[h.steps + lane] = (u8)k;
+                    moved = true;
+                    h.steps += (unsigned)r; h.nb = nbp + (unsigned)r;
+                    n_flush++;
+                    res = flush_(true, lane < nbp ? pend : ext);
+                    if (res) break;
+                } else {
+                    if (nbp) { res = flush(); if (res) break; }                   // states still pending are looked up before anything new happens (EV_PEND / EV_BATCH)
+                    if ((int)lane < r && h.steps + lane < room) slog[h.steps + lane] = (u8)k;
+                    moved = true;
+                    if (fr0) {
+                        if ((int)lane < r) wv.or_visited(q);
+                        h.steps += (unsigned)r;
+                    } else {
+                        h.steps += (unsigned)r; h.nb = (unsigned)r;
+                        n_flush++;
+                        res = flush_(true, myst);
+                        if (res) break;
+                    }
+                }
+                d_jump += (unsigned)r;
+                wv.pl = wv.bcast(q, r - 1); wv.lastk = (int)wv.bcast((unsigned)k, r - 1); h.allow = 0xffu & ~(0x80u >> wv.lastk);
+                idx = (unsigned)((int)idx + dir * r);
+                if (!go_on) break;
+            }
+            if (moved) {
+                wv.codes_done = h.steps; wv.marks_done = h.steps; last_jump_end = wv.pl;
+                if (!res) { wv.have = false; wv.reload = true; wv.place(h.steps); }      // a fresh window around the new cursor (the old one lacks the marks of the stretch)
+            } else if (!res) wv.unflag_cursor(h.steps);
+            return res;
+        };
+#endif
         while (true) {
             if (h.steps >= room) { over = true; break; }
             unsigned lim = (h.steps & ~63u) + 64u;                    // the records of 64 steps fit the lanes: codes and marks leave at every multiple of 64
@@ -698,7 +805,10 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             int ev = wv.run(h, slog, room);
             n_ev++;
             if (ev == EV_DEAD) {
-                const int f = wv.resume_flagged(h.steps);             // GPU: a flagged window cell stops the loop the same way
+                int f = wv.resume_flagged(h.steps);                   // GPU: a flagged window cell stops the loop the same way
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (f == 3) { ended = chain_jump(); if (ended) break; f = 1; }       // end pixel of a listed chain: the forced stretch ahead in one go (or not: then the flag is out of the way)
+#endif
                 if (f == 1) {                                         // window re-placed (or a stale flag cleared): go on
                     if (h.steps == stall_steps && ++stall > 8u) { stalled = true; break; }     // ... unless nothing moves: a bug, never a hang
                     if (h.steps != stall_steps) { stall_steps = h.steps; stall = 0; }
@@ -736,7 +846,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     if (stalled && wv.leader()) *A.overflow = 2;                   // internal error: the host reports it instead of retrying
     if (A.dbg && wv.leader()) {
         unsigned long long* d = A.dbg + 16ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
-        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3;     // cycle counts: ORIP_WALK_PROF builds only
+        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3; d[15] = d_jump;     // cycle counts: ORIP_WALK_PROF builds only
     }
 }
 
