@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 thread_local int orip_tls_lane = 0;
+int orip_alloc_dbg = 0;
 
 void orip_enter(orip_ctx* c) {
     if (c) hipSetDevice(c->device);      // cheap (thread-local in the runtime); not cached here: the host application may switch devices too
@@ -14,6 +15,7 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
     // one hardware queue per lane where the runtime still accepts it (HIP multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues by
     // default, and kernels that share a queue run one after the other): only effective when this is the process's first HIP call
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    orip_alloc_dbg = getenv("ORIP_ALLOC_DBG") != nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2;   // no GPU: fail loudly, there is no CPU path
     if (device_id < 0 || device_id >= ndev) return -3;

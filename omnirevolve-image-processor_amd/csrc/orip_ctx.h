@@ -29,12 +29,14 @@ typedef uint8_t u8;
 
 #define ORIP_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
 
+extern int orip_alloc_dbg;      // ORIP_ALLOC_DBG: log every (re)allocation -- in steady state there must be none (hipFree waits for the whole device)
 // Growable device buffer; contents are NOT preserved across growth unless keep=true.
 struct DBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes, hipStream_t s = 0, bool keep = false) {
         if (bytes <= cap) return hipSuccess;
+        if (orip_alloc_dbg) fprintf(stderr, "[alloc] %p: %zu -> %zu bytes%s\n", (void*)this, cap, bytes, p ? " (hipFree: device-wide wait)" : "");
         size_t ncap = bytes + bytes / 4 + 256;
         void* np_ = nullptr;
         hipError_t e = hipMalloc(&np_, ncap);
@@ -135,6 +137,7 @@ struct orip_ctx {
     LaneRes ln[ORIP_MAX_LAYERS + 2];      // 0: raster stages; l + 1: layer l; ORIP_LANE_CROSS: stage 10
     std::atomic<int> lane_owner[ORIP_MAX_LAYERS + 2];   // 1 while a call holds the lane (LaneGuard); lane 0 is not claimed
     orip_params10 p10{}; bool p10_ready = false;   // stage 10 between orip_dedup_cross_begin and the per-layer calls
+    size_t hw_cross_off = 0, hw_cross_pts = 0;      // largest kept-line list of stage 10 so far: the buffers it swaps with the layers' LINES_CROSS slots never have to grow again
     bool cross_unordered[ORIP_MAX_LAYERS] = {false};   // LINES_CROSS of the layer still waits for its travel reorder (orip_dedup_cross_layer_deferred)
     void* prep04 = nullptr;               // stage-04 state between orip_contours_prepare and orip_contours_layer (raster04.hip)
     std::mutex mu;

@@ -499,7 +499,12 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
         if (reorder_now) { ORIP_TRY(vreorder(c, keepl, Lout, 10)); c->cross_unordered[layer] = false; }
         else {
             if (keepl.n == 0) { HIPC(c, keepl.off.ensure(64)); HIPC(c, hipMemsetAsync(keepl.off.p, 0, 8, LN(c).stream)); }
-            std::swap(keepl.off, Lout.off); std::swap(keepl.pts, Lout.pts); Lout.n = keepl.n; Lout.total = keepl.total;
+            // The buffers change hands (lane temporary <-> the layer's slot).  Whatever comes back is grown to the largest list seen so far NOW,
+            // while nothing is running on it, so that no later layer finds a too small buffer in the middle of its serial tail: growing means
+            // hipFree, and hipFree waits for every stream of the device (4 of them cost 4.5 ms per step before this).
+            c->hw_cross_off = std::max(c->hw_cross_off, (size_t)(keepl.n + 1) * 8 + 64); c->hw_cross_pts = std::max(c->hw_cross_pts, (size_t)std::max<int64_t>(keepl.total, 1) * 8 + 64);
+            std::swap(keepl.off, Lout.off); std::swap(keepl.pts, Lout.pts); Lout.n = keepl.n; Lout.total = keepl.total; Lout.set_explicit();
+            HIPC(c, keepl.off.ensure(c->hw_cross_off)); HIPC(c, keepl.pts.ensure(c->hw_cross_pts));
             c->cross_unordered[layer] = true;
         }
         auto t3 = tdbg ? now() : t0;
