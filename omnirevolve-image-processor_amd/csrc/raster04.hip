@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void k_write_walks(WalkArgs A, int layer, const
 }
 // lengths of the layer's walks (slots [slot0, slot0 + n)); walks that ended inside a recorded trajectory get their closing point settled here.
 // opc: own points (n_own + 1) << 32 | tail pieces of a kept walk (one scan sizes both arrays of the walk-coded form)
+__global__ void k_totals_flag(const int* __restrict__ over, unsigned* __restrict__ pad_of_total) { *pad_of_total = (unsigned)*over; }
 struct WSum {       // what one walk slot adds to the layer's list: one scan sizes and places everything
     unsigned long long pts; unsigned paths, own, pieces, pad;
     __host__ __device__ WSum operator+(const WSum& o) const { WSum r; r.pts = pts + o.pts; r.paths = paths + o.paths; r.own = own + o.own; r.pieces = pieces + o.pieces; r.pad = 0; return r; }
@@ -152,7 +153,7 @@ struct WSum {       // what one walk slot adds to the layer's list: one scan siz
 __global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, unsigned n, WSum* __restrict__ ws) {
     unsigned i = blockIdx.x * 256 + threadIdx.x;
     WSum s; s.pts = 0; s.paths = 0; s.own = 0; s.pieces = 0; s.pad = 0;
-    if (i < n) {
+    if (i < n && !*A.overflow) {                       // (logs of a trace that ran out of room are not followed: the host retries it)
         WalkInfo w = A.winfo[slot0 + i];
         if (w.flags & 2u) { walk_close_tail(A, PlainReader(), slot0 + i, w); A.winfo[slot0 + i] = w; }
         if (w.len_kept) { s.pts = w.len_kept; s.paths = 1u; s.own = w.n_own + 1u; s.pieces = vwalk_pieces(A.logbuf, PlainReader(), w, [](unsigned, unsigned, unsigned, unsigned) {}); }
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void k_winfo_lens(WalkArgs A, unsigned slot0, 
 // blockIdx.x = component of the layer, blockIdx.y = slice of its entries
 __global__ __launch_bounds__(256) void k_ent_fill(WalkArgs A, unsigned c0, unsigned log_shift, int2* __restrict__ lxy, unsigned* __restrict__ ent_idx, unsigned* __restrict__ cnt, unsigned cap) {
     __shared__ unsigned base_s;
+    if (*A.overflow) return;
     const unsigned c = c0 + blockIdx.x;
     const unsigned used = A.log_used[c];
     const unsigned per = (used + gridDim.y - 1) / gridDim.y, t0 = blockIdx.y * per, t1 = min(used, t0 + per);
@@ -627,14 +629,46 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     const size_t plane = (size_t)R.A.plane;
     dim3 block(256);
     int* d_over = LN(c).flags.as<int>() + 20;
+    // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
+    // Nothing waits for the trace first: the sizing kernels are enqueued behind it and the one read below brings its overflow flag along
+    // with the totals (an overflowed trace -- rare: the logs hold 64 entries per skeleton pixel -- is redone with larger logs).
+    const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
+    const size_t ns1 = (size_t)nslots + 1;
+    HIPC(c, LN(c).vtmp[4].ensure(ns1 * 2 * sizeof(WSum) + 256));
+    WSum* ws = LN(c).vtmp[4].as<WSum>(); WSum* wo = ws + ns1;
+    WalkStore& WS = c->wstore[layer];
+    WSum h_tot; unsigned log_shift = 0; WalkArgs A;
     for (;;) {
-        int over = 0;
-        HIPC(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, LN(c).stream));
-        HIPC(c, hipStreamSynchronize(LN(c).stream));
-        if (!over) break;
-        if (over == 2) ORIP_FAIL(c, "internal error: the walker of layer %d stopped making progress", layer);
-        hipLaunchKernelGGL(k_clear_visited_layer, dim3(cdiv(Ml, 256)), block, 0, LN(c).stream, R.A.st + plane * layer, R.A.lin + b0, (int64_t)Ml);   // retry with larger logs
-        ORIP_TRY(trace_launch(c, R, layer, R.F[layer] * 4));
+    log_shift = (unsigned)((size_t)R.F[layer] * b0 + (size_t)64 * c0);
+    A = R.A;                        // the layer's logs as the trace addressed them (walk_close_tail / vwalk_pieces follow the recorded trajectories)
+    A.logbuf = WS.log.as<unsigned>() - 4 * (size_t)log_shift;
+    A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
+    A.cap_factor = R.F[layer]; A.overflow = d_over;
+    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, ws);
+    {
+        size_t bytes = 0; WSum zero; zero.pts = 0; zero.paths = zero.own = zero.pieces = zero.pad = 0;
+        HIPC(c, rocprim::exclusive_scan(nullptr, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
+        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
+        HIPC(c, rocprim::exclusive_scan(LN(c).tmpF.p, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
+    }
+    A.overflow = d_over;
+    hipLaunchKernelGGL(k_totals_flag, dim3(1), dim3(1), 0, LN(c).stream, d_over, &wo[nslots].pad);
+    HIPC(c, hipMemcpyAsync(&h_tot, wo + nslots, sizeof(WSum), hipMemcpyDeviceToHost, LN(c).stream));
+    // pixels of the log entries in use (needs nothing from the scan: it runs while the host waits for the totals)
+    {
+        const unsigned NCl = c1 - c0;
+        WS.ent_cap = (int64_t)8 * Ml + 64;                       // a component logs at most one entry per (pixel, incoming direction)
+        HIPC(c, WS.lxy.ensure(((size_t)R.F[layer] * Ml + (size_t)64 * NCl + 8) * 8 + 64));
+        HIPC(c, WS.ent_idx.ensure((size_t)WS.ent_cap * 4 + 64));
+        HIPC(c, WS.cnt.ensure(64));
+        HIPC(c, hipMemsetAsync(WS.cnt.p, 0, 4, LN(c).stream));
+        hipLaunchKernelGGL(k_ent_fill, dim3(NCl, 8), block, 0, LN(c).stream, A, c0, log_shift, WS.lxy.as<int2>(), WS.ent_idx.as<unsigned>(), WS.cnt.as<unsigned>(), (unsigned)WS.ent_cap);
+    }
+    HIPC(c, hipStreamSynchronize(LN(c).stream));
+    if (!h_tot.pad) break;
+    if (h_tot.pad == 2) ORIP_FAIL(c, "internal error: the walker of layer %d stopped making progress", layer);
+    hipLaunchKernelGGL(k_clear_visited_layer, dim3(cdiv(Ml, 256)), block, 0, LN(c).stream, R.A.st + plane * layer, R.A.lin + b0, (int64_t)Ml);   // retry with larger logs
+    ORIP_TRY(trace_launch(c, R, layer, R.F[layer] * 4));
     }
     if (getenv("ORIP_WALK_DBG")) {
         const unsigned NCl = c1 - c0;
@@ -650,37 +684,6 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
                           layer, d[8], d[9], d[10], d[11], d[12], d[13]);
         if (d[8]) fprintf(stderr, "[walk prof]   inside the look-ups: duplicate check %llu cycles\n", d[14]);
     }
-    // offsets: exclusive scans over the layer's walk slots (slot order == output order: components by rank, endpoint walks then leftovers, each in raster order)
-    const unsigned nslots = 2u * Ml, sl0 = 2u * b0;
-    const size_t ns1 = (size_t)nslots + 1;
-    HIPC(c, LN(c).vtmp[4].ensure(ns1 * 2 * sizeof(WSum) + 256));
-    WSum* ws = LN(c).vtmp[4].as<WSum>(); WSum* wo = ws + ns1;
-    WalkStore& WS = c->wstore[layer];
-    const unsigned log_shift = (unsigned)((size_t)R.F[layer] * b0 + (size_t)64 * c0);
-    WalkArgs A = R.A;                        // the layer's logs as the trace addressed them (walk_close_tail / vwalk_pieces follow the recorded trajectories)
-    A.logbuf = WS.log.as<unsigned>() - 4 * (size_t)log_shift;
-    A.steplog = LN(c).vtmp[9].as<u8>() - ((size_t)R.F[layer] * b0 + (size_t)256 * c0);
-    A.cap_factor = R.F[layer];
-    hipLaunchKernelGGL(k_winfo_lens, dim3(cdiv(nslots + 1, 256)), block, 0, LN(c).stream, A, sl0, nslots, ws);
-    {
-        size_t bytes = 0; WSum zero; zero.pts = 0; zero.paths = zero.own = zero.pieces = zero.pad = 0;
-        HIPC(c, rocprim::exclusive_scan(nullptr, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
-        HIPC(c, LN(c).tmpF.ensure(bytes + 16));
-        HIPC(c, rocprim::exclusive_scan(LN(c).tmpF.p, bytes, ws, wo, zero, ns1, rocprim::plus<WSum>(), LN(c).stream));
-    }
-    WSum h_tot;
-    HIPC(c, hipMemcpyAsync(&h_tot, wo + nslots, sizeof(WSum), hipMemcpyDeviceToHost, LN(c).stream));
-    // pixels of the log entries in use (needs nothing from the scan: it runs while the host waits for the totals)
-    {
-        const unsigned NCl = c1 - c0;
-        WS.ent_cap = (int64_t)8 * Ml + 64;                       // a component logs at most one entry per (pixel, incoming direction)
-        HIPC(c, WS.lxy.ensure(((size_t)R.F[layer] * Ml + (size_t)64 * NCl + 8) * 8 + 64));
-        HIPC(c, WS.ent_idx.ensure((size_t)WS.ent_cap * 4 + 64));
-        HIPC(c, WS.cnt.ensure(64));
-        HIPC(c, hipMemsetAsync(WS.cnt.p, 0, 4, LN(c).stream));
-        hipLaunchKernelGGL(k_ent_fill, dim3(NCl, 8), block, 0, LN(c).stream, A, c0, log_shift, WS.lxy.as<int2>(), WS.ent_idx.as<unsigned>(), WS.cnt.as<unsigned>(), (unsigned)WS.ent_cap);
-    }
-    HIPC(c, hipStreamSynchronize(LN(c).stream));
     const unsigned long long h_pts = h_tot.pts; const unsigned h_paths = h_tot.paths, h_own = h_tot.own, h_pieces = h_tot.pieces;
     // ---- the contours of the layer in walk-coded form (walker.h): nothing is expanded here
     DPolys& P = c->polys[ORIP_SLOT_CONTOURS][layer];

@@ -329,8 +329,13 @@ __device__ __forceinline__ float nn_d2(int32_t ax, int32_t ay, int32_t bx, int32
     float dx = __fsub_rn((float)ax, (float)bx), dy = __fsub_rn((float)ay, (float)by);
     return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
 }
-__global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ ends, int n, int seed, int rule07, uint8_t* __restrict__ used,
+// sel[0] = seed polyline, sel[1] = coordinate-range flags of k_ends_fit16 (both written on the device just before: the host does not wait for
+// them).  The candidates are all enqueued and each decides from sel[1] whether it is the one that runs: (flags & skip_if) != 0 -> not
+// this one; need_any != 0 && (flags & need_any) == 0 -> not this one either.
+#define ORIP_NN_GATE(sel, skip_if, need_any) const int fl_ = (sel)[1]; if ((fl_ & (skip_if)) != 0 || ((need_any) != 0 && (fl_ & (need_any)) == 0)) return; const int seed = (sel)[0];
+__global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07, uint8_t* __restrict__ used,
                                                      int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    ORIP_NN_GATE(sel, skip_if, need_any)
     __shared__ unsigned long long wbest[16];
     __shared__ int cxs, cys;
     const int tid = threadIdx.x;
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ e
 
 // LDS-resident variant: end points as int16 quads + a state byte per polyline live in LDS (n <= 16000), so a greedy step costs
 // two barriers and a few LDS reads instead of global-memory round trips.  Same selection rule, same tie-break.
-__global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict__ ends, int n, int seed, int rule07,
+__global__ __launch_bounds__(1024) void k_greedy_nn_lds(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07,
                                                          int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    ORIP_NN_GATE(sel, skip_if, need_any)
     extern __shared__ __align__(16) unsigned char smem[];
     short4* P = reinterpret_cast<short4*>(smem);                 // (sx, sy, ex, ey)
     uint8_t* stt = smem + (size_t)n * sizeof(short4);            // bit0 used, bit1 closed
@@ -441,8 +447,9 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v)
 // distance is below the squared gap between the cursor and the nearest unscanned cell (every unscanned entry is at least that far,
 // so it can neither win nor tie), or the window covers the grid.  The chain of steps is strictly serial and a step looks at a few
 // dozen entries, so ONE wavefront runs it: no barriers, no cross-wave exchange, and no other wave competing for the SIMD.
-__global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
+__global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07, int G,
                                                         int32_t* __restrict__ order, uint8_t* __restrict__ flips, unsigned long long* __restrict__ dbg) {
+    ORIP_NN_GATE(sel, skip_if, need_any)
     extern __shared__ __align__(16) unsigned char smem[];
     // end points relative to the bounding-box origin (0 <= v < 2^14: differences, hence all float distances, are unchanged);
     // bit 15 of .x = used, bit 15 of .y = closed under rule07 (entered at the start only)
@@ -592,15 +599,15 @@ __global__ __launch_bounds__(256) void k_gather_pts(const GatherDesc* __restrict
     }
 }
 // Builds dst (DPolys) from descriptors (device array of n descs).  lens/off scratch in ctx->tmpE.
-static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* src, DPolys& dst) {
+static int vgather(orip_ctx* c, const GatherDesc* d, int64_t n, const int32_t* src, DPolys& dst, int64_t known_total = -1) {
     dst.n = n; dst.total = 0; dst.set_explicit();
     HIPC(c, dst.off.ensure((size_t)(n + 1) * 8 + 64));
     if (n == 0) { HIPC(c, hipMemsetAsync(dst.off.p, 0, 8, LN(c).stream)); return 0; }
     HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 8 + 64));
     hipLaunchKernelGGL(k_gather_lens, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, d, n, LN(c).tmpE.as<int64_t>());
     ORIP_TRY(vscan_excl<int64_t>(c, LN(c).tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
-    int64_t total = 0;
-    ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
+    int64_t total = known_total;
+    if (total < 0) ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
     dst.total = total;
     HIPC(c, dst.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
     if (total > 0) hipLaunchKernelGGL(k_gather_pts, dim3((unsigned)cdiv(total, 4096)), dim3(256), 0, LN(c).stream, d, n, src, dst.off.as<int64_t>(), dst.pts.as<int32_t>(), total);
@@ -621,7 +628,8 @@ __global__ __launch_bounds__(256) void k_view_select(const GatherDesc* __restric
     o.first = s.rev ? s.first + s.len - (unsigned)g.len : s.first;
     out[k] = o; lens[k] = g.len;
 }
-static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst) {
+// known_total >= 0: the caller knows the number of points selected (e.g. a permutation of the whole source list): no host read
+static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst, int64_t known_total = -1) {
     VSrc vs_; ORIP_TRY(vsrc_of(c, src, vs_));
     dst.n = n; dst.total = 0;
     dst.virt = true; dst.pts_ok = false; dst.vident = false; dst.vlayer = src.vlayer; dst.vepoch = src.vepoch;
@@ -632,16 +640,16 @@ static int vgather_views(orip_ctx* c, const GatherDesc* d, int64_t n, const DPol
     HIPC(c, LN(c).tmpE.ensure((size_t)(n + 1) * 8 + 64));
     hipLaunchKernelGGL(k_view_select, dim3(cdiv(n + 1, 256)), dim3(256), 0, LN(c).stream, d, n, vs_.view, vs_.walk, dst.vview.as<VView>(), LN(c).tmpE.as<int64_t>());
     ORIP_TRY(vscan_excl<int64_t>(c, LN(c).tmpE.as<int64_t>(), dst.off.as<int64_t>(), (size_t)n + 1));
-    int64_t total = 0;
-    ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
+    int64_t total = known_total;
+    if (total < 0) ORIP_TRY(vread(c, &total, dst.off.as<int64_t>() + n));
     dst.total = total;
     HIPC(c, hipGetLastError());
     return 0;
 }
 // selection out of a list of either kind
-static int vgather_list(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst) {
-    if (is_coded(src)) return vgather_views(c, d, n, src, dst);
-    return vgather(c, d, n, src.pts.as<int32_t>(), dst);
+static int vgather_list(orip_ctx* c, const GatherDesc* d, int64_t n, const DPolys& src, DPolys& dst, int64_t known_total = -1) {
+    if (is_coded(src)) return vgather_views(c, d, n, src, dst, known_total);
+    return vgather(c, d, n, src.pts.as<int32_t>(), dst, known_total);
 }
 // explicit points of a list of either kind: 4096 consecutive output points per block (as k_gather_pts)
 template <class Src>
@@ -709,8 +717,9 @@ __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restri
 //   * "no unscanned cell can be nearer" is an integer test: floor(d2) + 1 <= gap^2 - gap^2 / 2^18 - 1 (the three float roundings of a
 //     squared distance stay below 2^-22 relative): conservative, so at worst one more round is scanned, never a wrong winner;
 //   * results leave through a VGPR (one lane per step, 64 at a time).
-__global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict__ ends, int n, int seed, int rule07, int G,
+__global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07, int G,
                                                         int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+    ORIP_NN_GATE(sel, skip_if, need_any)
     extern __shared__ __align__(16) unsigned char smem[];
     uint2* P = reinterpret_cast<uint2*>(smem);                                     // .x = sx | sy << 16, .y = ex | ey << 16; bit 15 of sx: used, bit 15 of sy: closed (rule07)
     unsigned* cst = reinterpret_cast<unsigned*>(P + n);                            // cst[0] = 0, cst[c + 1] = end of cell c
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
 
 // Greedy reorder of a whole DPolys list into dst.  kind: 7 -> 07 rules (arcLength closed seed), 8 -> 08 (_poly_perimeter seed), 10 -> 10 (arcLength open seed)
 // under_greedy (optional): called right after the greedy kernel has been enqueued, with the features of the source list (device
-// array, complete: the host has read the seed).  The chain of greedy steps keeps ONE wave busy for milliseconds, so work that does not
+// array; complete once the lane's event ev2 has fired -- the host no longer waits in front of the chain, so the hook's stream must).  The chain of greedy steps keeps ONE wave busy for milliseconds, so work that does not
 // depend on the order can be issued to the lane's side stream from there (stage 08's front: vector08.hip: prefetch08).
 typedef int (*ReorderHook)(orip_ctx* c, void* arg, DPolys& src, const PolyFeat* feat);
 static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook under_greedy = nullptr, void* hook_arg = nullptr) {
@@ -870,9 +879,6 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     HIPC(c, hipMemsetAsync(d_seed + 1, 0, 4, LN(c).stream));
     hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
     hipLaunchKernelGGL(k_ends_fit16, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, ends, (int)n, d_seed + 1);
-    int hs[2] = {0, 0};
-    ORIP_TRY(vread(c, hs, d_seed, 2));
-    const int seed = hs[0];
     const size_t lds = (size_t)n * 9 + 16;
     // grid side: as fine as LDS allows (cells are powers of two, so twice the side is four times fewer candidates per window),
     // but not many more cells than polylines
@@ -886,23 +892,27 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
         orip_max_lds(k_greedy_nn_fast, 158 * 1024, attr_err);
     });
     if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(greedy kernels) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
-    if (n >= 64 && n <= 16000 && !hs[1] && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID")) {      // hs[1] == 0: every coordinate in [-2^14, 2^14)
+    // Seed and coordinate-range flags stay on the device: every kernel that may have to run is enqueued and picks itself from the flags
+    // (bit 0: a coordinate beyond int16 -> the global-memory kernel; bit 1: beyond 15 bits -> no grid).  No host round trip in front of the chain.
+    if (under_greedy) HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));      // everything the hook's side-stream work reads (features, ends) is complete at this point of the stream
+    const bool grid_ok = n >= 64 && n <= 16000 && lds_grid <= 158 * 1024 && !getenv("ORIP_NN_NOGRID");
+    const bool lds_ok = n <= 16000;
+    const int r07 = kind == 7 ? 1 : 0;
+    {
         ProfScope ps(c, "k_greedy_nn");
         unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
-        if (dbg || getenv("ORIP_NN_OLDGRID")) hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips, dbg);
-        else hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, G, order, flips);
-        if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
-    } else if (n <= 16000 && !(hs[1] & 1)) {
-        ProfScope ps(c, "k_greedy_nn");
-        hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, order, flips);
-    } else {
-        ProfScope ps(c, "k_greedy_nn");
-        hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, seed, kind == 7 ? 1 : 0, used, order, flips);
+        if (grid_ok) {
+            if (dbg || getenv("ORIP_NN_OLDGRID")) hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, dbg);
+            else hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips);
+            if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
+        }
+        if (lds_ok) hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, d_seed, 1, grid_ok ? 2 : 0, r07, order, flips);   // with a grid candidate: only when the grid bowed out
+        hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, d_seed, 0, lds_ok ? 1 : 0, r07, used, order, flips);
     }
     if (under_greedy) ORIP_TRY(under_greedy(c, hook_arg, src, feat));
     hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
     HIPC(c, hipGetLastError());
-    return vgather_list(c, desc, n, src, dst);
+    return vgather_list(c, desc, n, src, dst, src.total);      // every polyline of the source, whole: the same number of points
 }
 
 }  // namespace

@@ -1196,6 +1196,7 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
     HIPC(c, F.ord.ensure((size_t)n * 16 + 64));
     {
         StreamSwap sw(LN(c));                       // LN(c).stream is the side stream from here to the end of the block
+        HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev2, 0));      // stage 07's features (feat07) and its use of the shared scratch end here (vreorder)
         PolyFeat* ff = F.feat.as<PolyFeat>(); float* per_rev = reinterpret_cast<float*>(ff + n); RsInfo* inf = F.info.as<RsInfo>(); float* cum = F.cum.as<float>();
         VSrc sS; ORIP_TRY(vsrc_of(c, S, sS));
         // A2 first (the long serial chains): cumulative lengths of both readings; long polylines longest first
@@ -1240,7 +1241,8 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
     unsigned nt = 0, nk = 0;
-    ORIP_TRY(vread(c, &nt, tap_scan + n)); ORIP_TRY(vread(c, &nk, keep_scan + n));
+    HIPC(c, hipMemcpyAsync(&nt, tap_scan + n, 4, hipMemcpyDeviceToHost, LN(c).stream));      // both counts, one wait
+    ORIP_TRY(vread(c, &nk, keep_scan + n));
     if (nt) {
         HIPC(c, tapbuf.ensure((size_t)(tap_base + nt) * 8 + 64, LN(c).stream, true));
         hipLaunchKernelGGL(k_compact_desc, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, is_tap, tap_scan, n, (const GatherDesc*)nullptr, (GatherDesc*)nullptr, tap_xy, tapbuf.as<int2>() + tap_base);

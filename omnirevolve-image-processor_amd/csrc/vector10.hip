@@ -102,7 +102,7 @@ int orip_runs_to_polys(orip_ctx* c, const int2* spt, const uint8_t* sflag, unsig
     hipLaunchKernelGGL(k_run_starts, dim3(cdiv(n_slots, 256)), dim3(256), 0, LN(c).stream, sflag, n_slots, start);
     ORIP_TRY(vscan_excl<unsigned>(c, start, start_scan, n_slots));
     unsigned a[2];
-    ORIP_TRY(vread(c, &a[0], start_scan + (n_slots - 1)));
+    HIPC(c, hipMemcpyAsync(&a[0], start_scan + (n_slots - 1), 4, hipMemcpyDeviceToHost, LN(c).stream));      // both words, one wait
     ORIP_TRY(vread(c, &a[1], start + (n_slots - 1)));
     unsigned n_runs = a[0] + a[1];
     if (n_runs == 0) return 0;
@@ -481,7 +481,8 @@ static int dedup_cross_layer_impl(orip_ctx* c, int src_layer, int layer, bool re
             ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)cut.n + 1));
             ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)cut.n + 1));
             unsigned a = 0, b = 0;
-            ORIP_TRY(vread(c, &a, tap_scan + cut.n)); ORIP_TRY(vread(c, &b, keep_scan + cut.n));
+            HIPC(c, hipMemcpyAsync(&a, tap_scan + cut.n, 4, hipMemcpyDeviceToHost, LN(c).stream));      // both counts, one wait
+            ORIP_TRY(vread(c, &b, keep_scan + cut.n));
             n_tap_lines = a;
             if (b) {
                 hipLaunchKernelGGL(k_compact_sel, dim3(cdiv(cut.n, 256)), dim3(256), 0, LN(c).stream, is_keep, keep_scan, cut.n, cut.off.as<int64_t>(), kd, (const int2*)nullptr, (int2*)nullptr);
