@@ -7,13 +7,16 @@ synthetic 4096 x 4096, 8-layer image (BASELINE.json; SURVEY 8(d) generator, seed
 
 A "step" is one pass of the whole hot path over one image whose pixels are already resident in HBM (orip_set_image is
 outside the timed region).  Nothing is cached between steps: every step re-runs the k-means fit, all raster stages, the
-contour walk, both dedup stages and the plot ordering; the op rows come back to the host, the line points stay on the GPU.
+contour walk, both dedup stages and the plot ordering, and ends with every op list AND its line points in host memory
+("... to all ops lists in host memory"; r03: the fetch is inside the timed region of `value`).
 With N > 1 the single image is processed by all ranks together (colour-layer sharding), so the scaling is
 "strong"; the timed region is bracketed by a barrier + device sync and the max over ranks is reported.
 
 One JSON line on rank 0.  Extra objects:
-  inclusive    -- the same step with the upload of the image and the fetch of every op list AND its line points inside the
-                  timed region: SURVEY 8(d)'s definition "host pixels -> ops lists in host memory" (PCIe-inclusive; never `value`)
+  inclusive    -- the same step with the upload of the image inside the timed region as well: SURVEY 8(d)'s "host pixels -> ops
+                  lists in host memory" (PCIe-inclusive on both ends; `value` has the input resident, as the bench contract asks)
+  c2           -- BASELINE config C2 in the same run: 2048 x 2048, 8 layers, stages 02 + 03 only, with the raster kernel groups'
+                  measured GB/s against the HBM peak
   roofline     -- the kernel group with the largest device time in a profiled step: algorithmic bytes (DESIGN.md
                   "Algorithmic bytes") / mean duration measured with HIP events on the library's own stream
   kernel_groups-- the same figures for every raster kernel group
@@ -36,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "omnirevolve-image-processor_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def csrc_digest() -> str:
@@ -60,7 +63,8 @@ def kernel_groups(H, W, K, n_points):
         "blur_sobel_nms": (["k_blur_sobel_nms"], K * px // 8 + K * px // 4, "launch", "1 bit mask in + 2 bits (candidate, strong planes) out per pixel per layer"),
         "thin_bits": (["k_thin_bits"], 2 * K * px // 8, "launch", "1 bit in + 1 bit out per pixel per layer and sub-iteration; bit planes of 2 MB per layer: cache traffic"),
         "skel_state": (["k_skel_state"], K * px // 8 + 2 * K * px, "launch", "1 bit in + skeleton byte + state byte out per pixel per layer"),
-        "stage04_write": (["k_write_walks"], 8 * n_points, "step", "8 B per emitted contour point (SURVEY 8d), one launch per layer"),
+        "stage04_write": (["k_write_walks"], 8 * n_points, "step", "8 B per emitted contour point (SURVEY 8d), one launch per layer; r03: the points are emitted in walk-coded "
+                          "form (own points + tail records), so this launch (k_vown) only writes the distinct points -- the figure is the algorithmic one, not bytes moved"),
         "stage04_trace": (["k_trace", "k_write_walks"], K * px + 8 * n_points, "step",
                           "K B/px skeleton state read once + 8 B per emitted contour point (SURVEY 8d); k_trace is a serial dependent chain "
                           "per skeleton component (one wave each), so its time is latency, not bandwidth"),
@@ -85,6 +89,9 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(f"bench.py --gpus {args.gpus} does not start ranks itself: launch it with `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                 f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...` (one rank per GPU)")
     if world != args.gpus and world > 1:
         args.gpus = world
     dist = None; coll_device = None; backend = None; n_vis = 1
@@ -132,12 +139,12 @@ def main():
         return P.run_path_sharded(dev, cfg, H, W, rank, world, coll_device, fetch_lines=fetch, comm=comm)
 
     for _ in range(args.warmup):
-        step()
+        step(fetch=True)
     barrier()
     t0 = time.perf_counter()
     n_ops = 0
     for _ in range(args.steps):
-        n_ops = step()
+        n_ops = step(fetch=True)      # ops AND line points of every layer end in host memory inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -165,7 +172,8 @@ def main():
         barrier()
         inc = max_over_ranks(time.perf_counter() - t1)
         inclusive = {"ms_per_step": round(inc / n_inc * 1e3, 2), "value": round((H * W / 1e6) * n_inc / inc, 4), "unit": "Mpx/s", "steps": n_inc,
-                     "note": "upload of the 3 B/px image + the path + fetch of every layer's op rows and line points, per step (PCIe inclusive)"}
+                     "note": "upload of the 3 B/px image + the path + fetch of every layer's op rows and line points, per step (PCIe inclusive on both ends; "
+                             "`value` differs only by the upload)"}
 
     # ---- roofline leg: one extra profiled step (HIP events around every launch on the library's stream); not timed above
     roofline = None; groups_out = {}
@@ -194,7 +202,7 @@ def main():
             e = groups_out[best]
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py; rocprofv3 cannot run
             # inside the timed process).  The file is only believed when it was collected on exactly these kernel sources.
-            traffic = None; traffic_note = None
+            traffic = None; traffic_note = None; traffic_detail = None
             try:
                 pmf = json.load(open(PMC_FILE))
                 names = [n for k in e["kernels"] for n in PMC_NAMES.get(k, [k])]
@@ -203,13 +211,16 @@ def main():
                 elif not all(n in pmf["kernels"] for n in names) or not (H == 4096 and K == 8 and world == 1 and args.upto == 12):
                     traffic_note = f"{os.path.relpath(PMC_FILE, ROOT)} does not cover this configuration / these kernels: refused"
                 else:
-                    traffic = int(sum(2 * pmf["kernels"][n]["fetch_bytes_per_launch_raw"] + pmf["kernels"][n]["write_bytes_per_launch"] for n in names))
-                    traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE "
-                                    "per launch, separate rocprofv3 --pmc passes of this command")
+                    raw_f = int(sum(pmf["kernels"][n]["fetch_bytes_per_launch_raw"] for n in names)); raw_w = int(sum(pmf["kernels"][n]["write_bytes_per_launch"] for n in names))
+                    traffic = 2 * raw_f + raw_w
+                    traffic_detail = {"fetch_size_raw": raw_f, "fetch_scale": 2, "write_size_raw": raw_w, "estimate": traffic,
+                                      "calibration": "the factor 2 is calibrated for wide coalesced reads only (MI355X_MICROARCH.md, HBM section); the byte- and dword-granular "
+                                                     "reads of k_trace are uncalibrated: the scaled figure is an ESTIMATE, the raw counters are what was measured"}
+                    traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: 2 x FETCH_SIZE + WRITE_SIZE per launch (estimate, see traffic_detail), separate rocprofv3 --pmc passes of this command")
             except (OSError, KeyError, ValueError) as ex:
                 traffic_note = f"no usable PMC file ({type(ex).__name__})"
             roofline = {"kernel": "+".join(e["kernels"]), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": e["frac"], "traffic": traffic, "traffic_note": traffic_note, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
+                        "frac": e["frac"], "traffic": traffic, "traffic_detail": traffic_detail, "traffic_note": traffic_note, "avg_ms": e["avg_ms"], "algorithmic_bytes": e["algorithmic_bytes"]}
 
     # ---- pipelined leg (N = 1 only, reported next to `value`, never as `value`): M images in flight, one context and one host thread each.
     # A step alone leaves the card nearly idle while the walks of the heavy layers run; a second image fills that window.
@@ -247,6 +258,42 @@ def main():
         except Exception as ex:
             pipelined = {"error": f"{type(ex).__name__}: {ex}"}
 
+    # ---- BASELINE config C2 in the same run (rank 0, N = 1, default size only): 2048^2 x 8, stages 02 + 03, raster kernel groups vs the HBM peak
+    c2 = None
+    if rank == 0 and world == 1 and args.upto == 12 and H == 4096:
+        try:
+            H2 = W2 = 2048
+            img2 = synth_image(H2, W2, K)
+            dev.set_image(img2)
+
+            def step2():
+                centers, _ = dev.kmeans_fit(S.subsample_indices(H2 * W2), K)
+                dev.extract_layers(centers, want_counts=False)
+                S._detect_edges_resident(dev, cfg)
+                dev.sync()
+            step2()
+            t3 = time.perf_counter()
+            n2 = 5
+            for _ in range(n2):
+                step2()
+            dt2 = (time.perf_counter() - t3) / n2
+            dev.prof_enable(True); dev.prof_reset(); step2(); dev.prof_enable(False)
+            g2 = {}
+            for name, (kernels, nbytes, per, note) in kernel_groups(H2, W2, K, 0).items():
+                tot_ms = 0.0; launches = 0
+                for k in kernels:
+                    ms, n = dev.prof_get(k); tot_ms += ms; launches = max(launches, n)
+                if launches == 0 or name.startswith("stage04"):
+                    continue
+                gbs = nbytes * launches / (tot_ms * 1e-3) / 1e9
+                g2[name] = {"launches": launches, "avg_ms": round(tot_ms / launches, 4), "algorithmic_bytes": int(nbytes), "achieved_GBs": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5)}
+            kf_ms, kf_n = dev.prof_get("k_kmeans_fit")
+            c2 = {"workload": f"{W2}x{H2} BGR image, {K} colour layers, stages 02+03 only (BASELINE config 2)", "ms_per_step": round(dt2 * 1e3, 3),
+                  "value": round(H2 * W2 / 1e6 / dt2, 2), "unit": "Mpx/s", "steps": n2, "kmeans_fit_ms": round(kf_ms, 3) if kf_n else None, "kernel_groups": g2,
+                  "peak_GBs": HBM_PEAK_GBS}
+        except Exception as ex:
+            c2 = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- CPU baseline legs (rank 0, N = 1 only): the oracle as a "port", bounded sample, single thread and layer threads
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -274,9 +321,9 @@ def main():
             "n_gpus": min(world, max(1, n_vis)) if world > 1 else 1, "ranks": world, "backend": backend or "none",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8/i32 raster + f32/f64 geometry", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} BGR image, {K} colour layers, {stages}", "parallelism": f"layer-sharded x{args.gpus}",
+            "config": {"workload": f"{W}x{H} BGR image, {K} colour layers, {stages}", "parallelism": f"layer-sharded x{world}" if world > 1 else "one GPU, one pipeline per colour layer",
                        "ops_last_step_rank0": int(n_ops), "exchange": (comm.kind if comm is not None else "none")},
-            "inclusive": inclusive, "pipelined": pipelined, "roofline": roofline, "kernel_groups": groups_out, "cpu_baseline": cpu,
+            "inclusive": inclusive, "pipelined": pipelined, "roofline": roofline, "kernel_groups": groups_out, "c2": c2, "cpu_baseline": cpu,
         }
         if world > 1 and n_vis < world:
             out["note"] = f"{world} ranks shared {n_vis} visible GPU(s) (gloo rehearsal): NOT a multi-GPU scaling point"

@@ -50,17 +50,28 @@ extern "C" int orip_bcast_layer(orip_ctx* c, int root, int my_slot) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     hipStream_t s = LN(c).stream;
     DPolys& P = c->polys[ORIP_SLOT_LINES_INTRA][my_slot]; DTaps& T = c->taps[ORIP_TAPS_INTRA][my_slot];
+    // A rank that fails after the size row has gone round must not simply return: the others would wait in the payload broadcasts
+    // for ever.  Everything that can fail locally (expanding a walk-coded list, the size row's sanity, the allocations) is done
+    // BEFORE this rank joins the grouped broadcast; if any of it fails the communicator is aborted, which ends the peers' pending
+    // collectives with an error instead of a hang.
+    auto bail = [&](const char* what) -> int {
+        ncclCommAbort(comm); c->comm = nullptr;
+        ORIP_FAIL(c, "%s: communicator aborted so that the other ranks fail instead of hanging", what);
+    };
     int64_t sizes[3] = {0, 0, 0};
-    if (c->comm_rank == root) { sizes[0] = P.n; sizes[1] = P.total; sizes[2] = T.n; HIPC(c, hipMemcpyAsync(c->comm_sizes.p, sizes, sizeof(sizes), hipMemcpyHostToDevice, s)); }
+    if (c->comm_rank == root) {
+        if (orip_polys_materialize(c, P) != 0) return bail("expanding the layer's list failed on the root");
+        sizes[0] = P.n; sizes[1] = P.total; sizes[2] = T.n;
+        if (hipMemcpyAsync(c->comm_sizes.p, sizes, sizeof(sizes), hipMemcpyHostToDevice, s) != hipSuccess) return bail("staging the size row failed");
+    }
     NCCLC(c, ncclBroadcast(c->comm_sizes.p, c->comm_sizes.p, 3, ncclInt64, root, comm, s));
     if (c->comm_rank != root) {
-        HIPC(c, hipMemcpyAsync(sizes, c->comm_sizes.p, sizeof(sizes), hipMemcpyDeviceToHost, s));
-        HIPC(c, hipStreamSynchronize(s));
-        if (sizes[0] < 0 || sizes[1] < 0 || sizes[2] < 0) ORIP_FAIL(c, "corrupt size row from rank %d", root);
-        HIPC(c, P.off.ensure((size_t)(sizes[0] + 1) * 8 + 64));
-        HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(sizes[1], 1) * 8 + 64));
-        HIPC(c, T.xy.ensure((size_t)std::max<int64_t>(sizes[2], 1) * 8 + 64));
-        if (sizes[0] == 0) HIPC(c, hipMemsetAsync(P.off.p, 0, 8, s));
+        if (hipMemcpyAsync(sizes, c->comm_sizes.p, sizeof(sizes), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bail("reading the size row failed");
+        if (sizes[0] < 0 || sizes[1] < 0 || sizes[2] < 0 || sizes[0] > (int64_t)1 << 40 || sizes[1] > (int64_t)1 << 40) return bail("corrupt size row");
+        if (P.off.ensure((size_t)(sizes[0] + 1) * 8 + 64) != hipSuccess || P.pts.ensure((size_t)std::max<int64_t>(sizes[1], 1) * 8 + 64) != hipSuccess ||
+            T.xy.ensure((size_t)std::max<int64_t>(sizes[2], 1) * 8 + 64) != hipSuccess) return bail("no memory for the incoming layer");
+        P.set_explicit();
+        if (sizes[0] == 0 && hipMemsetAsync(P.off.p, 0, 8, s) != hipSuccess) return bail("clearing the offsets failed");
     }
     NCCLC(c, ncclGroupStart());
     if (sizes[0]) NCCLC(c, ncclBroadcast(P.off.p, P.off.p, (size_t)(sizes[0] + 1), ncclInt64, root, comm, s));

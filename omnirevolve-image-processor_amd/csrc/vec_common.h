@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
         float ds = nn_d2(sx, sy, cx, cy), de = nn_d2((int)e.z, (int)e.w, cx, cy);
         const bool cl = (e.y & 0x8000) != 0;
         const bool flip = cl ? false : !(ds <= de);
-        if (lane == 0) { reinterpret_cast<unsigned short*>(&P[bi])[0] = (unsigned short)(e.x | 0x8000); ring[step & 63] = (uint16_t)((bi << 1) | (flip ? 1 : 0)); }
+        if (lane == 0) { P[bi].x = (unsigned short)(e.x | 0x8000); ring[step & 63] = (uint16_t)((bi << 1) | (flip ? 1 : 0)); }
         if ((step & 63) == 63) { const unsigned v = ring[lane]; order[step - 63 + lane] = (int32_t)(v >> 1); flips[step - 63 + lane] = (uint8_t)(v & 1u); }
         if (cl || flip) { cx = sx; cy = sy; } else { cx = e.z; cy = e.w; }
         prev = bi;
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
         const bool cl = (w0 & 0x80000000u) != 0;
         const bool flip = cl ? false : !(ds <= de);
         const int fl = NNU(flip ? 1 : 0);
-        if (lane == 0) reinterpret_cast<unsigned short*>(&P[bi])[0] = (unsigned short)((w0 & 0xffffu) | 0x8000u);
+        if (lane == 0) P[bi].x = w0 | 0x8000u;                       // the used flag, through the type the entries are read as (lane 0 is the only writer)
         ringv = lane == (step & 63) ? (unsigned)((bi << 1) | fl) : ringv;
         if ((step & 63) == 63) { order[step - 63 + lane] = (int32_t)(ringv >> 1); flips[step - 63 + lane] = (uint8_t)(ringv & 1u); }
         if (cl || fl) { cx = sx; cy = sy; } else { cx = ex; cy = ey; }

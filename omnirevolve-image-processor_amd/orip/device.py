@@ -28,6 +28,13 @@ class Device:
         self.H = self.W = self.K = 0
 
     def close(self):
+        cached = getattr(self, "_comm", None)       # communicator of sharded steps (orip.parallel.comm_of)
+        if cached is not None and getattr(self, "h", None):
+            self._comm = None
+            try:
+                cached[1].close()
+            except Exception:
+                pass
         if getattr(self, "h", None):
             self.L.orip_destroy(self.h)
             self.h = None

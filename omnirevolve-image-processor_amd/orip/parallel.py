@@ -129,8 +129,9 @@ class RcclComm:
 
 
 class GlooComm:
-    """Test double / rehearsal: the same lists through host memory and torch.distributed (gloo)."""
-    kind = "gloo (host staging; rehearsal / CPU test double)"
+    """The same lists through torch.distributed broadcasts: packed on the host, broadcast on `coll_device` (this rank's GPU under the
+    nccl backend = RCCL over xGMI; host memory under gloo: the CPU tests and rehearsals with several ranks on one card)."""
+    kind = "torch.distributed broadcast (RCCL under the nccl backend, gloo otherwise; lists packed on the host)"
 
     def __init__(self, dev, coll_device="cpu"):
         self.dev = dev; self.coll_device = coll_device
@@ -149,11 +150,29 @@ class GlooComm:
 
 
 def make_comm(dev, rank: int, world: int, coll_device=None):
-    """RCCL when every rank has its own GPU (torch backend nccl), the gloo double otherwise."""
+    """The exchange of a sharded step.  Default: the layer lists travel through torch.distributed broadcasts (RCCL over xGMI when the
+    process group's backend is nccl and `coll_device` is this rank's GPU, gloo through host memory otherwise) -- the path every test
+    and rehearsal has run.  ORIP_EXCHANGE=rccl selects the broadcast inside liborip.so (orip_bcast_layer, slot to slot, no host
+    staging): it has only ever run with a one-rank communicator (no multi-GPU node was available to this build), so it is opt-in
+    until a multi-GPU run has passed once."""
+    import os
     import torch.distributed as dist
-    if dist.get_backend() == "nccl":
+    if os.environ.get("ORIP_EXCHANGE", "").lower() == "rccl" and dist.get_backend() == "nccl":
         return RcclComm(dev, rank, world)
     return GlooComm(dev, coll_device or "cpu")
+
+
+def comm_of(dev, rank: int, world: int, coll_device=None):
+    """The communicator of `dev`, created on first use and kept: orip_comm_init refuses a second communicator on one context, so a
+    sharded step must not build a new one every time it is called without `comm`."""
+    cached = getattr(dev, "_comm", None)
+    if cached is not None and cached[0] == (rank, world):
+        return cached[1]
+    if cached is not None:
+        cached[1].close()
+    comm = make_comm(dev, rank, world, coll_device)
+    dev._comm = ((rank, world), comm)
+    return comm
 
 
 def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None, fetch_lines: bool = False, comm=None):
@@ -188,7 +207,7 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
         res = S.run_layer_pipelines(dev, cfg, W, H, range(K), order, 12, tail)
         return sum(len(o) for o in res.values())
     if comm is None:
-        comm = make_comm(dev, rank, world, coll_device)
+        comm = comm_of(dev, rank, world, coll_device)       # cached on the device: a second sharded step reuses it
     mine = owned_layers(K, rank, world)              # global layer ids; held under local indices 0..len(mine)-1
     ready, errors = {}, []
     if mine:

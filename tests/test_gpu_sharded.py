@@ -59,6 +59,9 @@ def _worker(rank, world, port, q, cold=False):
             want = snapshot(range(K))
             dev.set_image(img)
             P.run_path_sharded(dev, cfg, H, W, rank, world, "cpu")
+            dev.set_image(img)
+            P.run_path_sharded(dev, cfg, H, W, rank, world, "cpu")     # a second sharded step without `comm`: the communicator is reused, not rebuilt
+            assert dev._comm is not None
             got = snapshot(mine)
         ok = True
         for g in mine:

@@ -1,4 +1,4 @@
-"""Idle gaps of the critical queue in one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) of a rocprofv3 --kernel-trace CSV: every gap of at least MIN_MS with the dispatches on either side
+"""Idle gaps of the critical queue in one run (ORIP_TRACE_RUN, default 1 = the first timed step; run bench.py with --in-flight 0 for traces: its runs are then warm-up, timed steps, the inclusive leg and last the roofline leg, which synchronises after every profiled kernel (with --in-flight 2 the pipelined leg and the C2 leg follow)) of a rocprofv3 --kernel-trace CSV: every gap of at least MIN_MS with the dispatches on either side
 (development aid: a gap is a host round trip, a wait for another queue, or host work).  usage: python tools/chain_gaps.py <dir-or-csv> [MIN_MS]"""
 import csv, glob, os, re, sys
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.08

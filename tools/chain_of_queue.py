@@ -1,4 +1,4 @@
-"""The dispatches of ONE queue (default: the one holding the longest k_trace) in one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) of a rocprofv3 --kernel-trace CSV, in order,
+"""The dispatches of ONE queue (default: the one holding the longest k_trace) in one run (ORIP_TRACE_RUN, default 1 = the first timed step; bench.py --in-flight 0: the runs are warm-up, timed steps, one inclusive leg, then the roofline leg, which synchronises after every profiled kernel; with --in-flight 2 the pipelined leg follows it) of a rocprofv3 --kernel-trace CSV, in order,
 with the idle gap before each and a per-kernel total (development aid).  usage: python tools/chain_of_queue.py <dir-or-csv> [MIN_MS] [QUEUE|-] [FROM_MS]"""
 import csv, glob, os, re, sys
 from collections import defaultdict

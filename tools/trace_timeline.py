@@ -1,4 +1,4 @@
-"""Timeline of one run (ORIP_TRACE_RUN, default 1 = the first timed step; the LAST run of a bench.py trace is its roofline leg, which synchronises after every profiled kernel) inside a rocprofv3 --kernel-trace CSV: dispatches after the last k_kmeans_fit launch that last
+"""Timeline of one run (ORIP_TRACE_RUN, default 1 = the first timed step; run bench.py with --in-flight 0 for traces: its runs are then warm-up, timed steps, the inclusive leg and last the roofline leg, which synchronises after every profiled kernel (with --in-flight 2 the pipelined leg and the C2 leg follow)) inside a rocprofv3 --kernel-trace CSV: dispatches after the last k_kmeans_fit launch that last
 longer than MIN_MS, by start time (development aid).  usage: python tools/trace_timeline.py <dir-or-csv> [MIN_MS]"""
 import csv, glob, os, re, sys
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
