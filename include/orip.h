@@ -121,7 +121,9 @@ int orip_get_skeleton(orip_ctx* ctx, int layer, uint8_t* skel_out); /* thinning_
 
 /* ---- polyline-list / tap-list slots ---- */
 int orip_polys_size(orip_ctx* ctx, int slot, int layer, int64_t* n_polys, int64_t* n_points);
-int orip_get_polys(orip_ctx* ctx, int slot, int layer, int64_t* off /* [n+1] */, int32_t* pts /* [n_points,2] */);
+/* pts may be NULL: offsets only (the CONTOURS / SCALED / SORTED lists of a resident chain are held as walk records and only expanded into
+ * int32 pairs when the points are asked for -- a heavy layer holds 10^8..10^9 of them) */
+int orip_get_polys(orip_ctx* ctx, int slot, int layer, int64_t* off /* [n+1] */, int32_t* pts /* [n_points,2] or NULL */);
 int orip_set_polys(orip_ctx* ctx, int slot, int layer, int64_t n_polys, const int64_t* off, const int32_t* pts);
 int orip_taps_size(orip_ctx* ctx, int which, int layer, int64_t* n);
 int orip_get_taps(orip_ctx* ctx, int which, int layer, int32_t* xy);

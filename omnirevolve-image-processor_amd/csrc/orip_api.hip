@@ -109,9 +109,9 @@ extern "C" int orip_get_polys(orip_ctx* c, int slot, int layer, int64_t* off, in
     ORIP_TRY(check_slot(c, slot, layer));
     DPolys& P = c->polys[slot][layer];
     if (P.n == 0) { off[0] = 0; return 0; }
-    ORIP_TRY(orip_polys_materialize(c, P));      // a walk-coded list (stages 04 / 05 / 07 of a resident chain) is expanded here, on request
+    if (pts) ORIP_TRY(orip_polys_materialize(c, P));      // a walk-coded list (stages 04 / 05 / 07 of a resident chain) is expanded here, on request
     HIPC(c, hipMemcpyAsync(off, P.off.p, (size_t)(P.n + 1) * 8, hipMemcpyDeviceToHost, LN(c).stream));
-    if (P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, LN(c).stream));
+    if (pts && P.total) HIPC(c, hipMemcpyAsync(pts, P.pts.p, (size_t)P.total * 8, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
 }

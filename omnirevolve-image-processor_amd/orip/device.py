@@ -197,6 +197,13 @@ class Device:
         self._ck(self.L.orip_get_polys(self.h, slot, layer, _p(off), _p(pts)))
         return off, pts[:t]
 
+    def get_polys_offsets(self, slot: int, layer: int) -> np.ndarray:
+        """off int64[n + 1] only: a walk-coded list is not expanded for this"""
+        n, _ = self.polys_size(slot, layer)
+        off = np.zeros(n + 1, np.int64)
+        self._ck(self.L.orip_get_polys(self.h, slot, layer, _p(off), None))
+        return off
+
     def get_polys(self, slot: int, layer: int) -> List[np.ndarray]:
         off, pts = self.get_polys_flat(slot, layer)
         return [pts[off[i]:off[i + 1]].reshape(-1, 1, 2) for i in range(len(off) - 1)]
