@@ -43,7 +43,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     DBuf* bufs[] = {&c->image, &c->labels, &c->masks, &c->edges, &c->skel, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->lab_tabs, &c->cref, &c->cpix};
     for (DBuf* b : bufs) b->release();
     for (auto& l : c->ln) {
-        l.tmpE.release(); l.tmpF.release(); l.flags.release(); l.canvas.release();
+        l.tmpE.release(); l.tmpF.release(); l.flags.release(); l.canvas.release(); l.pixbits.release();
         for (auto& v : l.vtmp) v.release();
         if (l.ev0) hipEventDestroy(l.ev0);
         if (l.ev1) hipEventDestroy(l.ev1);

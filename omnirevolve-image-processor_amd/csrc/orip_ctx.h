@@ -102,6 +102,8 @@ struct LaneRes {
     hipStream_t stream2 = 0;              // side stream of the lane (work that may overlap the main chain), fenced with ev2 / ev3
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     DBuf vtmp[12], tmpE, tmpF, flags, canvas;
+    DBuf pixbits;                         // stage 08-A: one bit per canvas pixel that is the rounded position of a sample
+    unsigned caps_hint = 0;               // distinct capsules of the lane's last stage-08-A run (sizes the next run's table)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DPolys tp[6];   // persistent temporaries of the vector stages (no hipFree in steady state: hipFree synchronises the device)
     // stage 08's order-independent front, computed on the side stream while stage 07's greedy chain runs (vector08.hip: prefetch08)

@@ -280,7 +280,7 @@ template <class Src>
 __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restrict__ cumoff, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
-                                                  const int2* __restrict__ hints) {
+                                                  const int2* __restrict__ hints, unsigned long long* __restrict__ pixbits, int Wq, unsigned* __restrict__ firstseq) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
     const int2 h0 = hints[blockIdx.x];
@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restr
     A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
     bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
     A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
+    if (pixbits && in) {       // the canvas is read at sample pixels only (k_caps_stamp_bits): mark the pixel, give it its "never stamped" value
+        unsigned long long* wp = &pixbits[(size_t)yi * Wq + (xi >> 6)]; const unsigned long long bit = 1ULL << (xi & 63);
+        if (!(*wp & bit)) atomicOr(wp, bit);
+        firstseq[(size_t)yi * W + xi] = 0xffffffffu;
+    }
     if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
 }
 
@@ -491,6 +496,46 @@ __global__ __launch_bounds__(256) void k_caps_stamp(const CapSlot* __restrict__ 
             }
         }
     }
+}
+
+// The canvas is only ever READ at the pixels of samples (k_accept_pre: "was my pixel stamped before my own pops?"), and those are a thin
+// set: the rounded sample positions, i.e. pixels on the paths.  k_samples sets one bit per sample pixel in a bit plane of the canvas
+// (12.5 MB, cache-resident) and gives those pixels their "never stamped" value; a capsule then visits the words of the plane its box
+// covers and tests / stamps only the set bits -- ~100 pixels instead of the ~1800 of its box, and no 400 MB clear of the canvas.
+__global__ __launch_bounds__(256) void k_caps_stamp_bits(const CapSlot* __restrict__ tab, unsigned long long tsize, int rad, unsigned* __restrict__ firstseq, int W, int H,
+                                                          const unsigned long long* __restrict__ pixbits, int Wq, unsigned* __restrict__ n_distinct) {
+    const int lane = threadIdx.x & 63;
+    const long long r2 = (long long)rad * rad;
+    unsigned long long wave = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((unsigned long long)gridDim.x * 256) >> 6;
+    unsigned mine = 0;
+    for (unsigned long long s0 = wave * 64; s0 < tsize; s0 += nwaves * 64) {
+        const uint4 sl = (s0 + lane < tsize) ? reinterpret_cast<const uint4*>(tab)[s0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        unsigned long long k = ((unsigned long long)sl.y << 32) | sl.x;
+        unsigned v = sl.z;
+        unsigned long long occ = __ballot(k != 0);
+        mine += (unsigned)__popcll(occ);
+        while (occ) {
+            int src = __ffsll((long long)occ) - 1; occ &= occ - 1;
+            unsigned long long kk = __shfl(k, src, 64) - 1ULL; unsigned seq = __shfl(v, src, 64);
+            unsigned long long a = kk >> 28, b = kk & ((1ULL << 28) - 1);
+            int x0 = (int)(a >> 14), y0 = (int)(a & 16383), x1 = (int)(b >> 14), y1 = (int)(b & 16383);
+            int bx0 = max(0, min(x0, x1) - rad), bx1 = min(W - 1, max(x0, x1) + rad), by0 = max(0, min(y0, y1) - rad), by1 = min(H - 1, max(y0, y1) + rad);
+            const int w0 = bx0 >> 6, nw = (bx1 >> 6) - w0 + 1, bh = by1 - by0 + 1;
+            for (int i = lane; i < nw * bh; i += 64) {
+                const int y = by0 + i / nw, wq = w0 + i % nw;
+                unsigned long long bits = pixbits[(size_t)y * Wq + wq];
+                const int xb = wq << 6;
+                if (xb < bx0) bits &= ~0ULL << (bx0 - xb);                         // the part of the word inside the box
+                if (xb + 63 > bx1) bits &= ~0ULL >> (xb + 63 - bx1);
+                while (bits) {
+                    const int j = __ffsll((long long)bits) - 1; bits &= bits - 1;
+                    const int x = xb + j;
+                    if (vs::in_capsule(x, y, x0, y0, x1, y1, r2)) { unsigned* q = &firstseq[(size_t)y * W + x]; if (*q > seq) atomicMin(q, seq); }   // (minima only decrease: a stale read costs a useless atomic at worst)
+                }
+            }
+        }
+    }
+    if (lane == 0 && mine) atomicAdd(n_distinct, mine);
 }
 
 // ================================================================= A5: _PointHash.near (08:85-93)
@@ -1285,6 +1330,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     struct Ref { DPolys& p; }; Ref kept0{LN(c).tp[0]}, cleaned{LN(c).tp[1]}, lines2{LN(c).tp[2]}, merged{LN(c).tp[3]};
     for (Ref* r : {&kept0, &cleaned, &lines2, &merged}) { r->p.n = 0; r->p.total = 0; r->p.set_explicit(); }
     int64_t nt0 = 0, nt2 = 0;
+    bool caps_counted = false;
     const bool tdbg = getenv("ORIP_TIME08") != nullptr;      // debug: per-phase wall times of this layer (adds stream syncs)
     std::string tlog; auto tprev = std::chrono::steady_clock::now();
     auto tick = [&](const char* name) {
@@ -1339,8 +1385,19 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             unsigned* ckin = LN(c).vtmp[5].as<unsigned>(); unsigned* ckout = ckin + MS; unsigned* cvin = ckout + MS; unsigned* cvout = cvin + MS;
             const double cell = P.grid_stride > 0 ? P.grid_stride : std::max(4.0, P.col_rad); const double inv = 1.0 / cell;
             int2* hints = (int2*)(LN(c).vtmp[5].as<uint8_t>() + (((size_t)MS * 24 + 63) & ~(size_t)63));
+            // canvas of first stamps: read at sample pixels only, so k_samples initialises exactly those and marks them in a bit plane (ORIP_CAPS_FULL: whole canvas, as before)
+            const bool bits_path = !getenv("ORIP_CAPS_FULL");
+            const int Wq = (W + 63) >> 6;
+            HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
+            unsigned* firstseq = LN(c).canvas.as<unsigned>();
+            unsigned long long* pixbits = nullptr;
+            if (bits_path) {
+                HIPC(c, LN(c).pixbits.ensure((size_t)Wq * H * 8 + 64));
+                pixbits = LN(c).pixbits.as<unsigned long long>();
+                HIPC(c, hipMemsetAsync(pixbits, 0, (size_t)Wq * H * 8, LN(c).stream));
+            } else HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
             hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, cumoff, cum, info, ord, sbase, nk, MS, step, nb, hints);
-            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints); }); }
+            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints, pixbits, Wq, firstseq); }); }
             hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
@@ -1374,16 +1431,17 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             }
             tick("tail");
             // ---- A4: de-duplicated capsules -> min-sequence canvas
-            HIPC(c, LN(c).canvas.ensure((size_t)W * H * 4 + 64));
-            unsigned* firstseq = LN(c).canvas.as<unsigned>();
-            HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
-            // The table only has to hold the DISTINCT capsules (retraced paths repeat theirs many times), which is not known in advance:
-            // start at a quarter of the sample count with bounded probing and grow on overflow; 2 * MS slots always suffice.
+            // The table only has to hold the DISTINCT capsules (retraced paths repeat theirs many times).  Their number is not known in advance:
+            // start from what this lane saw last time (a resident chain repeats itself; 3 slots per capsule), else from a quarter of the sample
+            // count, with bounded probing, and grow on overflow; 2 * MS slots always suffice.  A small table is a cache-resident one.
             unsigned long long tfull = 1024; while (tfull < 2ull * MS) tfull <<= 1;
-            unsigned long long tsize = 1024; while (tsize < MS / 4ull) tsize <<= 1;
+            unsigned long long tsize = 1024;
+            if (LN(c).caps_hint) { while (tsize < 3ull * LN(c).caps_hint) tsize <<= 1; } else { while (tsize < MS / 4ull) tsize <<= 1; }
+            tsize = std::min(tsize, tfull);
             if (getenv("ORIP_CAPS_TINY")) tsize = 1024;            // test hook: exercise the growth path
             CapSlot* tab = nullptr;
             int* d_ovf = LN(c).flags.as<int>() + 62;
+            unsigned* d_dist = LN(c).flags.as<unsigned>() + 126;
             for (;; tsize = std::min(tfull, tsize * 4)) {
                 HIPC(c, LN(c).vtmp[4].ensure((size_t)tsize * 16 + 64));
                 tab = LN(c).vtmp[4].as<CapSlot>();
@@ -1394,7 +1452,14 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 int ovf = 0; ORIP_TRY(vread(c, &ovf, d_ovf));
                 if (!ovf) break;
             }
-            { ProfScope ps(c, "k_caps_stamp"); hipLaunchKernelGGL(k_caps_stamp, dim3((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384)), dim3(256), 0, LN(c).stream, tab, tsize, P.brush_forbid / 2, firstseq, W, H); }
+            HIPC(c, hipMemsetAsync(d_dist, 0, 4, LN(c).stream));
+            {
+                ProfScope ps(c, "k_caps_stamp");
+                const dim3 sg((unsigned)std::min<unsigned long long>(tsize / 64 / 4 + 1, 16384));
+                if (bits_path) hipLaunchKernelGGL(k_caps_stamp_bits, sg, dim3(256), 0, LN(c).stream, tab, tsize, P.brush_forbid / 2, firstseq, W, H, pixbits, Wq, d_dist);
+                else hipLaunchKernelGGL(k_caps_stamp, sg, dim3(256), 0, LN(c).stream, tab, tsize, P.brush_forbid / 2, firstseq, W, H);
+            }
+            caps_counted = bits_path;
             tick("caps");
             // ---- A5 / A6: cheap test of every sample, then _PointHash.near for the survivors
             {
@@ -1605,7 +1670,10 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     tick("gather");
     // ---- C
     ORIP_TRY(vreorder(c, *fin, OUT, 8));
+    unsigned h_dist = 0;
+    if (caps_counted) HIPC(c, hipMemcpyAsync(&h_dist, LN(c).flags.as<unsigned>() + 126, 4, hipMemcpyDeviceToHost, LN(c).stream));
     HIPC(c, hipStreamSynchronize(LN(c).stream));
+    if (caps_counted) { LN(c).caps_hint = h_dist; if (tdbg) { char b[48]; snprintf(b, sizeof b, " [caps distinct %u]", h_dist); tlog += b; } }
     tick("reorder");
     if (tdbg) fprintf(stderr, "[time08] layer %d (in %lld polys %lld pts, kept %lld pts, cleaned %lld/%lld, lines2 %lld/%lld):%s\n", layer, (long long)S.n, (long long)S.total, (long long)kept0.p.total, (long long)cleaned.p.n, (long long)cleaned.p.total, (long long)lines2.p.n, (long long)lines2.p.total, tlog.c_str());
     return 0;
