@@ -281,28 +281,31 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restr
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
                                                   const int2* __restrict__ hints, unsigned long long* __restrict__ pixbits, int Wq, unsigned* __restrict__ firstseq) {
-    unsigned g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= MS) return;
+    __shared__ double shx[256], shy[256];
+    const unsigned g = blockIdx.x * 256 + threadIdx.x;
+    const bool act = g < MS;
+    double x = 0.0, y = 0.0; unsigned j = 0;
+    if (act) {
     const int2 h0 = hints[blockIdx.x];
     const bool last = blockIdx.x + 1 == gridDim.x;
     const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
     int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
-    unsigned i = ord[r]; unsigned j = g - sbase[r];
+    unsigned i = ord[r]; j = g - sbase[r];
     auto cu = src.cur(i); const float* s = cum + cumoff[i];
     RsInfo ri = info[i];
-    double x, y;
-    if (ri.pass) { const int2 q = cu.at(j); x = (double)(float)q.x; y = (double)(float)q.y; }
-    else {
-        double t = (double)sample_t(j, step);
-        const int64_t klo = (r == h0.x) ? h0.y : -1, khi = (!last && r == h1.x) ? h1.y : ri.n_eff - 2;
+    // position of sample jj of this polyline, its segment known to lie in [klo, khi]
+    auto pos = [&](unsigned jj, int64_t klo, int64_t khi, double& px, double& py) {
+        if (ri.pass) { const int2 q = cu.at(jj); px = (double)(float)q.x; py = (double)(float)q.y; return; }
+        double t = (double)sample_t(jj, step);
         int64_t k = sample_seg(s, ri.n_eff, t, klo, khi);
         double sk = (double)s[k], sk1 = (double)s[k + 1];
         double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
         double a = __dsub_rn(1.0, u);
         const int2 p0 = cu.at(k), p1 = cu.at(k + 1);
-        x = __dadd_rn(__dmul_rn((double)(float)p0.x, a), __dmul_rn((double)(float)p1.x, u));
-        y = __dadd_rn(__dmul_rn((double)(float)p0.y, a), __dmul_rn((double)(float)p1.y, u));
-    }
+        px = __dadd_rn(__dmul_rn((double)(float)p0.x, a), __dmul_rn((double)(float)p1.x, u));
+        py = __dadd_rn(__dmul_rn((double)(float)p0.y, a), __dmul_rn((double)(float)p1.y, u));
+    };
+    pos(j, (r == h0.x) ? h0.y : -1, (!last && r == h1.x) ? h1.y : ri.n_eff - 2, x, y);
     long long xi = vs::round_half_even(x), yi = vs::round_half_even(y);
     A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
     bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
@@ -313,6 +316,14 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restr
         firstseq[(size_t)yi * W + xi] = 0xffffffffu;
     }
     if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
+    // distance to the predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147): the predecessor is the
+    // previous thread's sample; the first thread of a block computes it again
+    if (threadIdx.x == 0 && j > 0) { double px, py; pos(j - 1, -1, ri.n_eff - 2, px, py); A.dprev[g] = vs::norm2_f64(x - px, y - py); }
+    }
+    shx[threadIdx.x] = x; shy[threadIdx.x] = y;
+    __syncthreads();
+    if (act && threadIdx.x > 0) A.dprev[g] = j > 0 ? vs::norm2_f64(x - shx[threadIdx.x - 1], y - shy[threadIdx.x - 1]) : 0.0;
+    if (act && threadIdx.x == 0 && j == 0) A.dprev[g] = 0.0;
 }
 
 // distance of every sample to its predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
@@ -1398,7 +1409,6 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             } else HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
             hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, cumoff, cum, info, ord, sbase, nk, MS, step, nb, hints);
             { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints, pixbits, Wq, firstseq); }); }
-            hipLaunchKernelGGL(k_sample_dist, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A);
             tick("samples");
             // ---- A3
             {
