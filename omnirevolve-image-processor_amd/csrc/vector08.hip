@@ -232,9 +232,16 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
         }
     }
 }
-__global__ __launch_bounds__(256) void k_rank_counts(const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t n, unsigned* __restrict__ mr) {
+// any_out: set when a sampled polyline reaches beyond the canvas (its samples lie inside the box of its points): only then can a sample be
+// off-canvas, and only then does "the previous in-canvas sample" (k_capprev) differ from "the previous sample"
+__global__ __launch_bounds__(256) void k_rank_counts(const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, int64_t n, unsigned* __restrict__ mr,
+                                                      const PolyFeat* __restrict__ feat, int W, int H, unsigned* __restrict__ any_out) {
     int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < n) mr[r] = info[ord[r]].m;
+    if (r < n) {
+        const unsigned i = ord[r]; const unsigned m = info[i].m;
+        mr[r] = m;
+        if (m) { const PolyFeat f = feat[i]; if (f.x0 < 0 || f.y0 < 0 || f.x1 >= W || f.y1 >= H) atomicOr(any_out, 1u); }
+    }
     if (r == n) mr[r] = 0;
 }
 __device__ __forceinline__ int64_t ub_u32v(const unsigned* a, int64_t n, unsigned v) {
@@ -470,9 +477,9 @@ __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigne
                                                       CapSlot* tab, unsigned long long tmask, int max_probe, int* __restrict__ overflow) {
     unsigned g = blockIdx.x * 256 + threadIdx.x;
     if (g >= MS) return;
-    int cp = capprev[g];
-    if (cp < 0) return;
     unsigned b = sbase[A.rank[g]];
+    int cp = capprev ? capprev[g] : (g > b ? (int)(g - b) - 1 : -1);      // capprev == nullptr: every sample is on the canvas, so the capsule runs from the previous sample
+    if (cp < 0) return;
     unsigned long long key = cap_key(A.xi[b + cp], A.yi[b + cp], A.xi[g], A.yi[g]);
     unsigned long long h = hash64(key) & tmask;
     for (int probe = 0;; probe++) {
@@ -1381,10 +1388,12 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen_long<decltype(sv)>, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
         }
         tick("cumlen");
-        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr);
+        HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));
+        hipLaunchKernelGGL(k_rank_counts, dim3(cdiv(nk + 1, 256)), dim3(256), 0, LN(c).stream, info, ord, nk, mr, feat, W, H, sbase + nk + 1);
         ORIP_TRY(vscan_excl<unsigned>(c, mr, sbase, (size_t)nk + 1));
-        unsigned MS = 0;
-        ORIP_TRY(vread(c, &MS, sbase + nk));
+        unsigned ms_out[2] = {0, 0};
+        ORIP_TRY(vread(c, ms_out, sbase + nk, 2));                // the sample count and, with it, whether any polyline leaves the canvas
+        const unsigned MS = ms_out[0]; const bool any_out = ms_out[1] != 0 || getenv("ORIP_CAPPREV_SCAN");
         if (MS > 0) {
             if (MS > 0x7ffffff0u) ORIP_FAIL(c, "too many samples");
             if (tdbg) { char b[48]; snprintf(b, sizeof b, " [MS %u]", MS); tlog += b; }
@@ -1429,6 +1438,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
                 HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream2));
             }
+            if (any_out)
             {
                 HIPC(c, LN(c).vtmp[8].ensure((size_t)MS * 8 + (size_t)(nk + 1) * 4 + 64));
                 unsigned* lastin = LN(c).vtmp[8].as<unsigned>();            // the prefix sums of the tail simulation are no longer needed
@@ -1439,6 +1449,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 HIPC(c, rocprim::inclusive_scan_by_key(LN(c).tmpF.p, bytes, A.rank, vin, lastin, (size_t)MS, rocprim::maximum<unsigned>(), rocprim::equal_to<unsigned>(), LN(c).stream));
                 hipLaunchKernelGGL(k_capprev, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, sbase, MS, A, lastin, capprev);
             }
+            else capprev = nullptr;       // every sample is on the canvas: "the previous in-canvas sample" is simply the previous one (k_caps_insert)
             tick("tail");
             // ---- A4: de-duplicated capsules -> min-sequence canvas
             // The table only has to hold the DISTINCT capsules (retraced paths repeat theirs many times).  Their number is not known in advance:
