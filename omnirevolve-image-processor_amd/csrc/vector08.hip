@@ -402,6 +402,84 @@ __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sb
         flush(cs, m - cs);
     }
 }
+// ---- the sequential simulation, replayed.  k_tail_par leaves for every sample the head the queue WOULD have if every comparison were
+// decided by exact arithmetic; the reference decides them with a float64 running sum whose roundings depend on the whole history of pushes
+// and pops.  Given the heads, that history is a fixed list of operations (+d[j], then -d[h] for every popped h), and its value after every
+// operation is a prefix sum with SEQUENTIAL rounding -- which 64 lanes evaluate as 63 wave-shifted adds (lane i is final after step i,
+// exactly as k_cumlen_long does for float32).  So a wavefront replays 64 operations at a time instead of deciding one comparison per
+// ~400 cycles, then checks the predicted heads against the reference's loop conditions with the running values it now has (after the last
+// pop: not > T; before it: > T).  Samples up to the first one that fails the check are final; that one is decided by the plain loop, and
+// the replay goes on from there with heads that can only have moved forward (running maximum).  Whatever the prediction was, a sample
+// is only ever committed when the reference's own conditions hold on the reference's own running value: the result is the sequential one.
+__device__ __forceinline__ double dpp_shr1_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__ sbase, int64_t n_rank, double T, SampleArrs A, unsigned* __restrict__ npop, const unsigned* __restrict__ only) {
+    __shared__ double ops[64], rr[64];
+    const int lane = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < n_rank; r += gridDim.x) {
+        if (only && !only[r]) continue;
+        const unsigned b = sbase[r], e = sbase[r + 1];
+        if (e <= b) continue;
+        const double* D = A.dprev + b; unsigned* NP = npop + b;
+        const unsigned m = e - b;
+        unsigned head = 0; double racc = 0.0;
+        unsigned j0 = 0;
+        // the plain loop for one sample (08:139-155), every lane the same
+        auto plain = [&](unsigned s) {
+            if (s > head) racc = __dadd_rn(racc, D[s]);
+            while (head <= s && racc > T) { head++; if (head <= s) racc = __dsub_rn(racc, D[head]); else racc = 0.0; }
+            if (lane == 0) NP[s] = head;
+        };
+        while (j0 < m) {
+            const unsigned s = j0 + (unsigned)lane; const bool valid = s < m;
+            unsigned hp = valid ? NP[s] : 0u;
+            hp = hp > head ? hp : head;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)hp, o, 64); if (lane >= o && t > hp) hp = t; }      // heads never move back: running maximum
+            unsigned prevh = (unsigned)__shfl_up((int)hp, 1, 64); if (lane == 0) prevh = head;
+            const unsigned np = hp - prevh;
+            unsigned inc = valid ? 1u + np : 0u, off = inc;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)off, o, 64); if (lane >= o) off += t; }
+            const unsigned long long fitm = __ballot(valid && off <= 64u);                 // (off is increasing over the valid lanes: a prefix)
+            const int m_fit = __popcll(fitm);
+            if (m_fit == 0) { plain(j0); j0++; continue; }                                 // a sample with more than 63 pops: the plain loop
+            off -= inc;                                                                    // exclusive
+            const unsigned total = (unsigned)__shfl((int)(off + inc), m_fit - 1, 64);
+            __syncthreads();
+            if (lane < m_fit) {
+                ops[off] = s > prevh ? D[s] : 0.0;                                         // the push adds nothing to an empty queue
+                for (unsigned t = 0; t < np; t++) ops[off + 1u + t] = -D[prevh + 1u + t];
+            }
+            __syncthreads();
+            const double v = (unsigned)lane < total ? ops[lane] : 0.0;
+            double d = lane == 0 ? __dadd_rn(racc, v) : v;
+            double pre = d;
+#pragma unroll
+            for (int q = 1; q < 64; q++) pre = __dadd_rn(dpp_shr1_f64(pre), d);
+            rr[lane] = pre;
+            __syncthreads();
+            bool bad = false;
+            if (lane < m_fit) {
+                const double after = rr[off + np];
+                bad = after > T || (np > 0u && !(rr[off + np - 1u] > T)) || hp > s;     // (a head beyond its own sample would be the emptied queue: plain loop)
+            }
+            const unsigned long long badm = __ballot(bad);
+            const int ncommit = badm ? __ffsll((long long)badm) - 1 : m_fit;
+            if (lane < ncommit) NP[s] = hp;
+            if (ncommit > 0) {
+                head = (unsigned)__shfl((int)hp, ncommit - 1, 64);
+                const unsigned last_op = (unsigned)__shfl((int)(off + np), ncommit - 1, 64);
+                racc = rr[last_op];
+            }
+            __syncthreads();
+            j0 += (unsigned)ncommit;
+            if (badm) { plain(j0); j0++; }
+        }
+    }
+}
+
 // Parallel form of the same simulation.  After sample j is pushed the queue holds samples head..j and tail_len is the sum of the
 // distances D[head+1..j]; the pops leave the smallest head with that sum <= tail_len_px (the sums shrink as head grows and a head
 // never moves back because D >= 0).  With S = per-polyline inclusive prefix sums of D (rocPRIM scan-by-key) the sum is S[j] - S[head],
@@ -1435,7 +1513,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 // the sequential redo only feeds the acceptance test (A6): it runs on the lane's side stream under the capsule / hash work
                 HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));
                 HIPC(c, hipStreamWaitEvent(LN(c).stream2, LN(c).ev2, 0));
-                hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
+                if (getenv("ORIP_TAIL_OLDSIM")) hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
+                else hipLaunchKernelGGL(k_tail_replay, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
                 HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream2));
             }
             if (any_out)
