@@ -417,7 +417,10 @@ __device__ __forceinline__ double dpp_shr1_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__ sbase, int64_t n_rank, double T, SampleArrs A, unsigned* __restrict__ npop, const unsigned* __restrict__ only) {
+    constexpr unsigned C = 1024u, RM = 2u * C - 1u;          // distances of the current chunk of C samples and of the one before it stay in LDS
     __shared__ double ops[64], rr[64];
+    __shared__ double Dl[2 * C];
+    __shared__ unsigned NPl[C];
     const int lane = threadIdx.x;
     for (int64_t r = blockIdx.x; r < n_rank; r += gridDim.x) {
         if (only && !only[r]) continue;
@@ -426,16 +429,29 @@ __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__
         const double* D = A.dprev + b; unsigned* NP = npop + b;
         const unsigned m = e - b;
         unsigned head = 0; double racc = 0.0;
-        unsigned j0 = 0;
+        unsigned j0 = 0, cb = 0;
+        // one memory round trip per chunk: 32 independent loads per lane in flight, then the LDS writes (a load inside the rounds below
+        // would cost the lone wave a round trip per 64 operations: most of the kernel's time)
+        auto fill = [&](unsigned c0) {
+            double td[16]; unsigned tn[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const unsigned idx = c0 + (unsigned)lane + 64u * u; td[u] = D[idx < m ? idx : m - 1u]; tn[u] = NP[idx < m ? idx : m - 1u]; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const unsigned idx = c0 + (unsigned)lane + 64u * u; Dl[idx & RM] = td[u]; NPl[idx & (C - 1u)] = tn[u]; }
+        };
+        auto dist = [&](unsigned idx) -> double { return (idx + C >= cb && idx < cb + C) ? Dl[idx & RM] : D[idx]; };      // [cb - C, cb + C) is in LDS
         // the plain loop for one sample (08:139-155), every lane the same
         auto plain = [&](unsigned s) {
-            if (s > head) racc = __dadd_rn(racc, D[s]);
-            while (head <= s && racc > T) { head++; if (head <= s) racc = __dsub_rn(racc, D[head]); else racc = 0.0; }
+            if (s > head) racc = __dadd_rn(racc, dist(s));
+            while (head <= s && racc > T) { head++; if (head <= s) racc = __dsub_rn(racc, dist(head)); else racc = 0.0; }
             if (lane == 0) NP[s] = head;
         };
+        fill(0);
+        __syncthreads();
         while (j0 < m) {
-            const unsigned s = j0 + (unsigned)lane; const bool valid = s < m;
-            unsigned hp = valid ? NP[s] : 0u;
+            if (j0 >= cb + C) { __syncthreads(); cb += C; fill(cb); __syncthreads(); }
+            const unsigned s = j0 + (unsigned)lane; const bool valid = s < m && s < cb + C;
+            unsigned hp = valid ? NPl[s & (C - 1u)] : 0u;
             hp = hp > head ? hp : head;
             for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)hp, o, 64); if (lane >= o && t > hp) hp = t; }      // heads never move back: running maximum
             unsigned prevh = (unsigned)__shfl_up((int)hp, 1, 64); if (lane == 0) prevh = head;
@@ -447,10 +463,9 @@ __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__
             if (m_fit == 0) { plain(j0); j0++; continue; }                                 // a sample with more than 63 pops: the plain loop
             off -= inc;                                                                    // exclusive
             const unsigned total = (unsigned)__shfl((int)(off + inc), m_fit - 1, 64);
-            __syncthreads();
             if (lane < m_fit) {
-                ops[off] = s > prevh ? D[s] : 0.0;                                         // the push adds nothing to an empty queue
-                for (unsigned t = 0; t < np; t++) ops[off + 1u + t] = -D[prevh + 1u + t];
+                ops[off] = s > prevh ? dist(s) : 0.0;                                      // the push adds nothing to an empty queue
+                for (unsigned t = 0; t < np; t++) ops[off + 1u + t] = -dist(prevh + 1u + t);
             }
             __syncthreads();
             const double v = (unsigned)lane < total ? ops[lane] : 0.0;
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__
             j0 += (unsigned)ncommit;
             if (badm) { plain(j0); j0++; }
         }
+        __syncthreads();
     }
 }
 
