@@ -184,7 +184,8 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = ord[rr];
         RsInfo rf = info[i], rb = info[n_polys + i];
-        const bool do_f = rf.n_eff > ORIP_LONG_CUM, do_b = rb.n_eff > ORIP_LONG_CUM;
+        // blockIdx.y picks the reading direction: two dependent chains interleaved in one wave cost their sum, two waves run side by side
+        const bool do_f = blockIdx.y == 0 && rf.n_eff > ORIP_LONG_CUM, do_b = blockIdx.y == 1 && rb.n_eff > ORIP_LONG_CUM;
         if (!do_f && !do_b) continue;
         auto cu = src.cur(i); const int64_t nfull = src.len(i);
         float* sf = cum + src.off[i]; float* sb = cum + rev_off + src.off[i];
@@ -212,17 +213,15 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
-                float df = (lane == 0) ? __fadd_rn(accf, curf[w]) : curf[w], db = (lane == 0) ? __fadd_rn(accb, curb[w]) : curb[w];
-                float pf_ = df, pb_ = db;
+                // ONE chain per wave (the direction this block was given): the strictly sequential float sums as 63 wave-shifted adds
+                const float cv = do_f ? curf[w] : curb[w];
+                float dv = (lane == 0) ? __fadd_rn(do_f ? accf : accb, cv) : cv;
+                float pv = dv;
 #pragma unroll
-                for (int j = 1; j < 64; j++) {
-                    pf_ = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pf_), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), df);
-                    pb_ = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pb_), 0x138, 0xf, 0xf, true)), db);
-                }
-                accf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_), 63));
-                accb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pb_), 63));
-                if (k < nsf) sf[k + 1] = pf_;
-                if (k < nsb) sb[k + 1] = pb_;
+                for (int j = 1; j < 64; j++)
+                    pv = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pv), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), dv);
+                const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 63));
+                if (do_f) { accf = last; if (k < nsf) sf[k + 1] = pv; } else { accb = last; if (k < nsb) sb[k + 1] = pv; }
             }
             lengths(ra, rb2, curf); lengths(rc, rd, curb);
         }
@@ -319,8 +318,7 @@ __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restr
     A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
     if (pixbits && in) {       // the canvas is read at sample pixels only (k_caps_stamp_bits): mark the pixel, give it its "never stamped" value
         unsigned long long* wp = &pixbits[(size_t)yi * Wq + (xi >> 6)]; const unsigned long long bit = 1ULL << (xi & 63);
-        if (!(*wp & bit)) atomicOr(wp, bit);
-        firstseq[(size_t)yi * W + xi] = 0xffffffffu;
+        if (!(*wp & bit) && !(atomicOr(wp, bit) & bit)) firstseq[(size_t)yi * W + xi] = 0xffffffffu;      // whoever sets the bit initialises the pixel: one write per distinct pixel, not per sample
     }
     if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
     // distance to the predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147): the predecessor is the
@@ -1361,7 +1359,7 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
-        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long2<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192)), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long2<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
         // A0 / A1: bounding box and numpy perimeter of the opened polyline, read forwards and backwards, in one pass over the points
         ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16 | 32, ff, per_rev));
         HIPC(c, hipGetLastError());
