@@ -23,23 +23,7 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
     orip_ctx* c = new orip_ctx();
     c->device = device_id;
     for (auto& o : c->lane_owner) o.store(0);
-    // ORIP_CU_SPLIT=1 (experiment): the layer lanes alternate between the two halves of the CUs, so that the small kernels of one heavy
-    // layer's chain do not queue behind the large kernels of the other's
-    const bool cu_split = getenv("ORIP_CU_SPLIT") != nullptr;
-    int lane_no = 0;
     for (auto& l : c->ln) {
-        const int ln_i = lane_no++;
-        if (cu_split && ln_i >= 1 && ln_i <= ORIP_MAX_LAYERS) {
-            uint32_t mask[8];
-            for (int w = 0; w < 8; w++) mask[w] = ((ln_i & 1) ? (w < 4) : (w >= 4)) ? 0xffffffffu : 0u;
-            if (hipExtStreamCreateWithCUMask(&l.stream, 8, mask) != hipSuccess || hipExtStreamCreateWithCUMask(&l.stream2, 8, mask) != hipSuccess) { delete c; return -5; }
-            hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
-            hipEventCreateWithFlags(&l.ev2, hipEventDisableTiming); hipEventCreateWithFlags(&l.ev3, hipEventDisableTiming);
-            if (l.flags.ensure(4096) != hipSuccess) { delete c; return -6; }
-            hipMemsetAsync(l.flags.p, 0, 4096, l.stream);
-            hipStreamSynchronize(l.stream);
-            continue;
-        }
         if (hipStreamCreate(&l.stream) != hipSuccess) { delete c; return -5; }
         hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
         if (hipStreamCreate(&l.stream2) != hipSuccess) { delete c; return -5; }
