@@ -487,6 +487,27 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         }
         { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     }
+    // ---- forced stretches (walker.h: ST_CHAIN), on the side stream underneath the component work below; the traces wait for ev3.
+    // Sized from the skeleton of the previous prepare of this context (a resident chain repeats itself), else from the pixel count: chains
+    // that do not fit are simply not listed (k_chain_build), the walker then steps through them as before.
+    R.chains = !getenv("ORIP_NO_CHAINS");
+    if (R.chains) {
+        const size_t m_guess = R.M ? (size_t)R.M + R.M / 4 + 4096 : (size_t)(n / 16 + 4096);
+        const unsigned cap_ends = (unsigned)std::min<size_t>(m_guess, 0x3fffffffu), cap_cpix = (unsigned)std::min<size_t>(2 * m_guess + 256, 0x7fffffffu);
+        HIPC(c, c->cref.ensure(plane * (size_t)K * 4 + 64));
+        HIPC(c, c->cpix.ensure((size_t)cap_cpix * 4 + (size_t)cap_ends * 4 + 64));
+        unsigned* cpix = c->cpix.as<unsigned>(); unsigned* ends = cpix + cap_cpix;
+        unsigned* d_cn = LN(c).flags.as<unsigned>() + 232;                          // {ends, cpix entries}
+        hipStream_t s2 = LN(c).stream2;
+        HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));                            // the state bytes
+        HIPC(c, hipStreamWaitEvent(s2, LN(c).ev2, 0));
+        HIPC(c, hipMemsetAsync(cpix, 0xff, (size_t)cap_cpix * 4, s2));             // sentinels everywhere, 64 of them in front of the first chain
+        const unsigned init[2] = {0u, 64u};
+        HIPC(c, hipMemcpyAsync(d_cn, init, 8, hipMemcpyHostToDevice, s2));
+        hipLaunchKernelGGL(k_chain_ends, dim3(cdiv(cdiv(n, 4), 256)), block, 0, s2, c->tmpC.as<u8>(), H, W, n, ends, d_cn, cap_ends);
+        hipLaunchKernelGGL(k_chain_build, dim3(cdiv(cap_ends, 64)), dim3(64), 0, s2, c->tmpC.as<u8>(), H, W, ends, d_cn, cap_ends, cpix, c->cref.as<unsigned>(), d_cn + 1, cap_cpix - 64u);
+        HIPC(c, hipEventRecord(LN(c).ev3, s2));
+    }
     // ---- components (from the thinned bit planes when they exist)
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
     if (!getenv("ORIP_THIN_BYTES") && !getenv("ORIP_CCL_BYTES")) ORIP_TRY(orip_ccl_bits(c, LN(c).vtmp[10].as<unsigned long long>(), c->tmpD.as<int>(), K));
@@ -508,22 +529,6 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     }
     R.M = M; R.NC = 0;
     if (M == 0) { HIPC(c, hipStreamSynchronize(LN(c).stream)); R.ready = true; return 0; }
-    // ---- forced stretches (walker.h: ST_CHAIN), on the side stream underneath the component work below; the traces wait for ev3
-    R.chains = !getenv("ORIP_NO_CHAINS");
-    if (R.chains) {
-        const unsigned cap_ends = M, cap_cpix = 2u * M + 256u;
-        HIPC(c, c->cref.ensure(plane * (size_t)K * 4 + 64));
-        HIPC(c, c->cpix.ensure((size_t)cap_cpix * 4 + (size_t)cap_ends * 4 + 64));
-        unsigned* cpix = c->cpix.as<unsigned>(); unsigned* ends = cpix + cap_cpix;
-        unsigned* d_cn = LN(c).flags.as<unsigned>() + 232;                          // {ends, cpix entries}
-        hipStream_t s2 = LN(c).stream2;
-        HIPC(c, hipMemsetAsync(cpix, 0xff, (size_t)cap_cpix * 4, s2));             // sentinels everywhere, 64 of them in front of the first chain
-        const unsigned init[2] = {0u, 64u};
-        HIPC(c, hipMemcpyAsync(d_cn, init, 8, hipMemcpyHostToDevice, s2));
-        hipLaunchKernelGGL(k_chain_ends, dim3(cdiv(cdiv(n, 4), 256)), block, 0, s2, c->tmpC.as<u8>(), H, W, n, ends, d_cn, cap_ends);
-        hipLaunchKernelGGL(k_chain_build, dim3(cdiv(cap_ends, 64)), dim3(64), 0, s2, c->tmpC.as<u8>(), H, W, ends, d_cn, cap_ends, cpix, c->cref.as<unsigned>(), d_cn + 1, cap_cpix - 64u);
-        HIPC(c, hipEventRecord(LN(c).ev3, s2));
-    }
     // keys / lin (double buffers for the sort)
     HIPC(c, LN(c).vtmp[0].ensure((size_t)M * 4 * 4 + 64));
     unsigned* keys_in = LN(c).vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
