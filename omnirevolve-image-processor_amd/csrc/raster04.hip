@@ -272,13 +272,15 @@ __global__ __launch_bounds__(256) void k_thin_bits04(const unsigned long long* _
     d[wi] = M & ~del;
 }
 // skeleton bytes (0 / 255) and state bytes (ST_FG | ST_END for degree 1 | ST_JUN for degree >= 3) from the thinned bit planes
-__global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long long* __restrict__ bits, u8* __restrict__ skel, u8* __restrict__ st, int H, int W, int Ww) {
+__global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long long* __restrict__ bits, u8* __restrict__ skel, u8* __restrict__ st, int H, int W, int Ww,
+                                                            unsigned long long* __restrict__ d2bits /* optional: the degree-2 pixels as a bit plane (k_chain_ends_bits) */) {
     const size_t nw = (size_t)H * Ww, w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (w0 >= nw) return;
     const unsigned long long* s = bits + nw * blockIdx.z;
     u8* sk = skel + (size_t)H * W * blockIdx.z; u8* so = st + (size_t)H * W * blockIdx.z;
     const int lane = threadIdx.x & 63;
     unsigned long long fg = 0, en = 0, ju = 0, d2 = 0;
+    auto wi_of = [](size_t a, int l) { return a + (size_t)l; };
     if (w0 + lane < nw) {
         const size_t wi = w0 + lane;
         fg = s[wi];
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
             ju = fg & (b2 | b3 | (b1 & b0));                  // three or more
             d2 = fg & ~b0 & b1 & ~b2 & ~b3;                   // exactly two: a walk passing through has no choice (walker.h: forced stretches)
         }
+        if (d2bits) d2bits[nw * blockIdx.z + wi_of(w0, lane)] = d2;
     }
     auto bc = [&](unsigned long long v, int j) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
@@ -333,6 +336,29 @@ __global__ __launch_bounds__(256) void k_chain_ends(const u8* __restrict__ st, i
             if ((v & ST_FG) && !(v & ST_DEG2)) end = true;
         }
         if (end) { const unsigned k = atomicAdd(n_ends, 1u); if (k < cap) ends[k] = ((unsigned)layer << 26) | (unsigned)p; }
+    }
+}
+// the same from the bit planes: a word of 64 pixels at a time -- ends = degree-2 pixels with a skeleton neighbour that is not degree-2
+__global__ __launch_bounds__(256) void k_chain_ends_bits(const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ d2bits, int H, int W, int Ww,
+                                                          unsigned* __restrict__ ends, unsigned* __restrict__ n_ends, unsigned cap) {
+    const size_t nw = (size_t)H * Ww, wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nw) return;
+    const unsigned long long* d2p = d2bits + nw * blockIdx.z;
+    const unsigned long long D = d2p[wi];
+    if (!D) return;
+    const unsigned long long* fgp = bits + nw * blockIdx.z;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww);
+    auto ND = [&](int yy, int xx) -> unsigned long long { return (yy < 0 || yy >= H || xx < 0 || xx >= Ww) ? 0ULL : (fgp[(size_t)yy * Ww + xx] & ~d2p[(size_t)yy * Ww + xx]); };      // skeleton, not degree 2
+    const unsigned long long U = ND(y - 1, xw), UL = ND(y - 1, xw - 1), UR = ND(y - 1, xw + 1), M = ND(y, xw), ML = ND(y, xw - 1), MR = ND(y, xw + 1);
+    const unsigned long long Dn = ND(y + 1, xw), DL = ND(y + 1, xw - 1), DR = ND(y + 1, xw + 1);
+    const unsigned long long any = U | ((U >> 1) | (UR << 63)) | ((U << 1) | (UL >> 63)) | ((M >> 1) | (MR << 63)) | ((M << 1) | (ML >> 63)) | Dn | ((Dn >> 1) | (DR << 63)) | ((Dn << 1) | (DL >> 63));
+    unsigned long long e = D & any;
+    while (e) {
+        const int j = __ffsll((long long)e) - 1; e &= e - 1;
+        const int x = xw * 64 + j;
+        if (x >= W) break;
+        const unsigned k = atomicAdd(n_ends, 1u);
+        if (k < cap) ends[k] = ((unsigned)blockIdx.z << 26) | ((unsigned)y * (unsigned)W + (unsigned)x);
     }
 }
 __global__ __launch_bounds__(64) void k_chain_build(u8* __restrict__ st, int H, int W, const unsigned* __restrict__ ends, const unsigned* __restrict__ n_ends, unsigned cap_ends,
@@ -450,6 +476,7 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K), block(256);
     const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
     HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
+    const unsigned long long* d2_plane = nullptr;   // degree-2 pixels as a bit plane (bit-plane thinning path only)
     if (!getenv("ORIP_THIN_BYTES")) {
         // bit planes: 2 MB per 4096^2 layer; pack, iterate, then skeleton and state bytes in one unpacking pass
         const int Ww = (W + 63) >> 6; const size_t nw = (size_t)H * Ww;
@@ -471,7 +498,8 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
             HIPC(c, hipStreamSynchronize(LN(c).stream));
             if (!(h_changed[0] && h_changed[1])) break;
         }
-        { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_bits_to_skel_state, gw, block, 0, LN(c).stream, bA, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W, Ww); }
+        { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_bits_to_skel_state, gw, block, 0, LN(c).stream, bA, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W, Ww, bB); }
+        d2_plane = bB;                                   // (the second thinning plane is free now)
     } else {
         // iteration 1 reads the edges; ping-pong skel <-> tmpB so that the result always lands in skel
         const u8* cur = c->edges.as<u8>();
@@ -504,7 +532,10 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         HIPC(c, hipMemsetAsync(cpix, 0xff, (size_t)cap_cpix * 4, s2));             // sentinels everywhere, 64 of them in front of the first chain
         const unsigned init[2] = {0u, 64u};
         HIPC(c, hipMemcpyAsync(d_cn, init, 8, hipMemcpyHostToDevice, s2));
-        hipLaunchKernelGGL(k_chain_ends, dim3(cdiv(cdiv(n, 4), 256)), block, 0, s2, c->tmpC.as<u8>(), H, W, n, ends, d_cn, cap_ends);
+        if (d2_plane) {
+            const int Ww = (W + 63) >> 6;
+            hipLaunchKernelGGL(k_chain_ends_bits, dim3((unsigned)cdiv((int64_t)H * Ww, 256), 1, K), block, 0, s2, LN(c).vtmp[10].as<unsigned long long>(), d2_plane, H, W, Ww, ends, d_cn, cap_ends);
+        } else hipLaunchKernelGGL(k_chain_ends, dim3(cdiv(cdiv(n, 4), 256)), block, 0, s2, c->tmpC.as<u8>(), H, W, n, ends, d_cn, cap_ends);
         hipLaunchKernelGGL(k_chain_build, dim3(cdiv(cap_ends, 64)), dim3(64), 0, s2, c->tmpC.as<u8>(), H, W, ends, d_cn, cap_ends, cpix, c->cref.as<unsigned>(), d_cn + 1, cap_cpix - 64u);
         HIPC(c, hipEventRecord(LN(c).ev3, s2));
     }
