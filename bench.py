@@ -72,7 +72,7 @@ def kernel_groups(H, W, K, n_points):
 
 
 # HIP-event label -> kernel names as rocprofv3 reports them (for the PMC cross-check)
-PMC_NAMES = {"k_trace": ["k_trace"], "k_write_walks": ["k_write_walks"], "k_lab_assign": ["k_lab_assign"], "k_blur_sobel_nms": ["k_blur_sobel_nms"],
+PMC_NAMES = {"k_trace": ["k_trace"], "k_write_walks": ["k_vown"], "k_lab_assign": ["k_lab_assign"], "k_blur_sobel_nms": ["k_blur_sobel_nms"],
              "k_morph_bits": ["k_morph_bits"], "k_thin_bits": ["k_thin_bits04"], "k_skel_state": ["k_bits_to_skel_state"]}
 
 
@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--layers", type=int, default=8, help="colour layers (BASELINE: 8)")
     ap.add_argument("--upto", type=int, default=12, choices=[3, 12], help="3: stages 02 + 03 only (BASELINE config C2, use with --size 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2", action="store_true", help="skip the BASELINE config C2 leg (counter passes: its 2048^2 launches would mix into the per-launch averages)")
     ap.add_argument("--in-flight", type=int, default=2, help="extra leg at N = 1: this many images in flight on the card, one context each (0 / 1: skip)")
     args = ap.parse_args()
 
@@ -260,7 +261,7 @@ def main():
 
     # ---- BASELINE config C2 in the same run (rank 0, N = 1, default size only): 2048^2 x 8, stages 02 + 03, raster kernel groups vs the HBM peak
     c2 = None
-    if rank == 0 and world == 1 and args.upto == 12 and H == 4096:
+    if rank == 0 and world == 1 and args.upto == 12 and H == 4096 and not args.no_c2:
         try:
             H2 = W2 = 2048
             img2 = synth_image(H2, W2, K)

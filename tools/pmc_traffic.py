@@ -35,7 +35,7 @@ for k in sorted(set(f) | set(w)):
     out[k] = {"launches": n, "fetch_kb_total": round(fs, 1), "write_kb_total": round(ws, 1),
               "fetch_bytes_per_launch_raw": int(fs * 1024 / max(fn, 1)), "write_bytes_per_launch": int(ws * 1024 / max(wn, 1))}
 json.dump({"csrc_digest": csrc_digest(), "unit_note": "raw counter x 1024 B; gfx950: FETCH_SIZE shows half the bytes of wide coalesced reads (MI355X_MICROARCH.md), other widths uncalibrated",
-           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (two steps + the profiled one per pass)",
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c2 --in-flight 0 (warm-up, timed, inclusive and profiled step per pass)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k in ("k_trace", "k_write_walks", "k_lab_assign", "k_nms_bits3", "k_morph_bits", "k_thin_bits04", "k_bits_to_skel_state", "k_greedy_nn_fast"):
+for k in ("k_trace", "k_vown", "k_lab_assign", "k_nms_bits3", "k_morph_bits", "k_thin_bits04", "k_bits_to_skel_state", "k_greedy_nn_fast"):
     if k in out: print(k, out[k])
