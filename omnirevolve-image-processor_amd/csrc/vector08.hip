@@ -96,7 +96,50 @@ __global__ __launch_bounds__(128) void k_cumlen(Src src, int64_t n_polys, double
     }
     info[i] = r;
 }
-template <class Src>
+
+// ---- float32 np.cumsum without the serial chain (r03).  While the running sum p stays inside one binade [2^e, 2^(e+1)) its ulp u is fixed and
+// p is a multiple of u, so fl(p + d) = p + R(d) with R(d) = d rounded to a multiple of u: an INTEGER increment that does not depend on p -- except
+// (i) when d lies exactly half-way between two multiples of u (round-half-even looks at p's last bit) and (ii) when the sum reaches 2^(e+1) (the ulp
+// doubles).  A window of 64 lengths is therefore one integer wave scan; the first lane where (i) or (ii) happens does ONE real float add from its
+// neighbour's exact sum, and the lanes behind it are scanned again in the new binade.  A polyline crosses a binade ~18 times and meets a tie only
+// where the low bits of a length happen to be 10..0 at the current ulp; every other window costs one scan instead of 63 dependent adds.
+// State: E = biased exponent of p (0: p == 0), M = 24-bit significand; both wave-uniform.  Lengths are finite and >= 0.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+#define ORIP_DPP_ADD(ctrl, rowmask) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false);
+    ORIP_DPP_ADD(0x111, 0xf) ORIP_DPP_ADD(0x112, 0xf) ORIP_DPP_ADD(0x114, 0xf) ORIP_DPP_ADD(0x118, 0xf)      // row_shr 1, 2, 4, 8
+    ORIP_DPP_ADD(0x142, 0xa) ORIP_DPP_ADD(0x143, 0xc)                                                          // row_bcast 15, 31
+#undef ORIP_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ float cum_window(float dval, int lane, unsigned& E, unsigned& M) {
+    const unsigned b = __float_as_uint(dval);
+    const unsigned Ed = b >> 23, Md = Ed ? ((b & 0x7fffffu) | 0x800000u) : 0u;
+    unsigned out = 0u; int first = 0;                 // lanes below `first` are final
+    for (;;) {
+        const int sh = (int)E - (int)Ed;
+        const unsigned sc = (unsigned)(sh < 0 ? 0 : (sh > 31 ? 31 : sh));
+        const unsigned rem = Md & ((1u << sc) - 1u), half = (1u << sc) >> 1;
+        const bool live = lane >= first;
+        const bool ev = live && (sh < 0 || (sc > 0u && rem == half));                 // d >= 2p, or a tie at this ulp
+        const unsigned r = (live && sh >= 0) ? (Md >> sc) + ((sc > 0u && rem > half) ? 1u : 0u) : 0u;
+        const unsigned S = wave_incl_scan_u32(r);
+        const unsigned long long em = __ballot(ev || (live && M + S >= 0x1000000u));
+        const int f = em ? __builtin_ctzll(em) : 64;
+        if (live && lane < f) out = (E << 23) | ((M + S) & 0x7fffffu);
+        if (f == 64) { M += (unsigned)__builtin_amdgcn_readlane((int)S, 63); break; }
+        const unsigned Mp = M + (f > first ? (unsigned)__builtin_amdgcn_readlane((int)S, f - 1) : 0u);
+        const float pprev = __uint_as_float((E << 23) | (Mp & 0x7fffffu));             // E == 0: M == 0, p == +0
+        const float pnew = __fadd_rn(pprev, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)b, f)));
+        const unsigned nb = __float_as_uint(pnew);
+        if (lane == f) out = nb;
+        E = nb >> 23; M = E ? ((nb & 0x7fffffu) | 0x800000u) : 0u;
+        first = f + 1;
+        if (first == 64) break;
+    }
+    return __uint_as_float(out);
+}
+__device__ __forceinline__ float cum_state_value(unsigned E, unsigned M) { return __uint_as_float((E << 23) | (M & 0x7fffffu)); }
+template <class Src, bool CHAIN>
 __global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, double step, float* __restrict__ cum, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
     const int lane = threadIdx.x;
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
@@ -106,7 +149,7 @@ __global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, do
         if (n <= ORIP_LONG_CUM) continue;
         auto cu = src.cur(i); float* s = cum + src.off[i];
         const int64_t nseg = n - 1;
-        float acc = 0.f;
+        float acc = 0.f; unsigned cE = 0u, cM = 0u;
         if (lane == 0) s[0] = 0.f;
         // four windows of 64 segment lengths per turn.  The POINTS of the next turn are requested before the serial chain of this one
         // runs and are only turned into lengths after it (using them earlier would make the chain wait for the loads after all).
@@ -125,14 +168,17 @@ __global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, do
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
-                // the strictly sequential float chain p[j] = p[j-1] + d[j] as 63 wave-shifted adds: after step j lane j is final, and a
-                // final lane recomputes the same sum from its final neighbour at every later step (lane 0 reads 0 and keeps 0 + d'[0])
-                float d = (lane == 0) ? __fadd_rn(acc, cur[w]) : cur[w];      // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
-                float pre = d;
+                float pre;
+                if (CHAIN) {
+                    // the strictly sequential float chain p[j] = p[j-1] + d[j] as 63 wave-shifted adds: after step j lane j is final, and a
+                    // final lane recomputes the same sum from its final neighbour at every later step (lane 0 reads 0 and keeps 0 + d'[0])
+                    float d = (lane == 0) ? __fadd_rn(acc, cur[w]) : cur[w];      // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
+                    pre = d;
 #pragma unroll
-                for (int j = 1; j < 64; j++)
-                    pre = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pre), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), d);
-                acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre), 63));      // padding lanes add +0: lane 63 holds the last real sum
+                    for (int j = 1; j < 64; j++)
+                        pre = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pre), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), d);
+                    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre), 63));      // padding lanes add +0: lane 63 holds the last real sum
+                } else { pre = cum_window(cur[w], lane, cE, cM); acc = cum_state_value(cE, cM); }
                 if (k < nseg) s[k + 1] = pre;
             }
             lengths(ra, rb, cur);
@@ -178,7 +224,7 @@ __global__ __launch_bounds__(128) void k_cumlen2(Src src, const PolyFeat* __rest
         info[dir ? n_polys + i : i] = r;
     }
 }
-template <class Src>
+template <class Src, bool CHAIN>
 __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
     const int lane = threadIdx.x;
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
@@ -190,7 +236,7 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
         auto cu = src.cur(i); const int64_t nfull = src.len(i);
         float* sf = cum + src.off[i]; float* sb = cum + rev_off + src.off[i];
         const int64_t nsf = do_f ? rf.n_eff - 1 : 0, nsb = do_b ? rb.n_eff - 1 : 0, nsm = nsf > nsb ? nsf : nsb;
-        float accf = 0.f, accb = 0.f;
+        float accf = 0.f, accb = 0.f; unsigned cE = 0u, cM = 0u;
         if (lane == 0) { if (do_f) sf[0] = 0.f; if (do_b) sb[0] = 0.f; }
         // per turn: 4 windows of 64 segment lengths in each direction; the points of the next turn are requested before this turn's chains run
         auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4], int2 (&c2)[4], int2 (&d2)[4]) {
@@ -213,14 +259,17 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
-                // ONE chain per wave (the direction this block was given): the strictly sequential float sums as 63 wave-shifted adds
+                // ONE direction per wave (the one this block was given)
                 const float cv = do_f ? curf[w] : curb[w];
-                float dv = (lane == 0) ? __fadd_rn(do_f ? accf : accb, cv) : cv;
-                float pv = dv;
+                float pv, last;
+                if (CHAIN) {                                          // the strictly sequential float sums as 63 wave-shifted adds
+                    float dv = (lane == 0) ? __fadd_rn(do_f ? accf : accb, cv) : cv;
+                    pv = dv;
 #pragma unroll
-                for (int j = 1; j < 64; j++)
-                    pv = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pv), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), dv);
-                const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 63));
+                    for (int j = 1; j < 64; j++)
+                        pv = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pv), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), dv);
+                    last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 63));
+                } else { pv = cum_window(cv, lane, cE, cM); last = cum_state_value(cE, cM); }
                 if (do_f) { accf = last; if (k < nsf) sf[k + 1] = pv; } else { accb = last; if (k < nsb) sb[k + 1] = pv; }
             }
             lengths(ra, rb2, curf); lengths(rc, rd, curb);
@@ -1359,7 +1408,9 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
-        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); hipLaunchKernelGGL(k_cumlen_long2<VSrc>, dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
+            if (chain) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl);
+            else hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
         // A0 / A1: bounding box and numpy perimeter of the opened polyline, read forwards and backwards, in one pass over the points
         ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16 | 32, ff, per_rev));
         HIPC(c, hipGetLastError());
@@ -1477,7 +1528,10 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         } else {
         HIPC(c, hipMemcpyAsync(cumoff, kept0.p.off.p, (size_t)(nk + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
-        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen_long<decltype(sv)>, dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
+        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
+            ORIP_WITH_SRC(c, kept0.p, sv, {
+                if (chain) hipLaunchKernelGGL((k_cumlen_long<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord);
+                else hipLaunchKernelGGL((k_cumlen_long<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
         }
         tick("cumlen");
         HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));

@@ -228,6 +228,34 @@ def test_stage08_tail_simulation_both_forms(dev, monkeypatch):
         assert same_polys(got_l, want_l), (seq, len(got_l), len(want_l))
 
 
+def test_stage08_cumulative_lengths_long_polylines(dev, monkeypatch):
+    """np.cumsum of float32 segment lengths (08:58) for polylines long enough for the wave kernels: the integer-scan form (binade by binade,
+    real float adds only at binade crossings and round-half ties) and the serial chain of wave-shifted adds must both give the oracle's lines."""
+    from orip import stages as S
+    rng = np.random.default_rng(2024)
+    cfgd = dict(O.DEFAULTS, pixels_per_mm=10)
+    cfg = _cfgobj(cfgd)
+    W, H = O.canvas_size(cfgd)
+    polys = []
+    for t in range(24):
+        m = int(rng.integers(150, 6000))
+        hi = (2, 3, 4, 12)[t % 4]                       # unit / diagonal steps, small mixed steps, and steps up to 17 px (many binades, many distinct lengths)
+        d = rng.integers(-hi + 1, hi, (m, 2))
+        p = np.cumsum(d, axis=0); p -= p.min(axis=0); p = p % np.array([W - 200, H - 200]) + 100      # wraps make a few long jumps as well
+        polys.append(p.astype(np.int32).reshape(-1, 1, 2))
+    base = np.cumsum(rng.integers(-1, 2, (300, 2)), axis=0) + np.array([W // 2, H // 2])
+    polys.append(np.concatenate([base, base[::-1]] * 40).astype(np.int32).reshape(-1, 1, 2))         # a bounce tail: the same cycle again and again
+    want_l, want_t = O.stage08_layer(polys, O.derived08(cfgd))
+    for chain in [False, True]:
+        if chain:
+            monkeypatch.setenv("ORIP_CUM_CHAIN", "1")
+        else:
+            monkeypatch.delenv("ORIP_CUM_CHAIN", raising=False)
+        got_l, got_t = S.dedup_layer(polys, cfg, dev)
+        assert got_t == want_t, chain
+        assert same_polys(got_l, want_l), (chain, len(got_l), len(want_l))
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_full_chain_image_to_ops_matches_reference(dev, tag):
     """Resident path 02 -> 12 from the image: final ops identical to the reference chain's ops.pkl."""

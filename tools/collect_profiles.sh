@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/be
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/r03_bench4096_kernel_stats.csv
 ORIP_TRACE_RUN=2 python tools/chain_of_queue.py $O/trace 0.25 > $O/r03_critical_queue_4096.txt 2>&1
 ORIP_TRACE_RUN=2 python tools/trace_timeline.py $O/trace > $O/r03_timeline_4096.txt 2>&1
+[ "$1" = "trace" ] && exit 0      # `bash tools/collect_profiles.sh trace`: the kernel trace and the two timelines only
 # 2. PMC passes (separate runs, --kernel-trace only next to --pmc)
 P="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c2 --in-flight 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $P > $O/pmc_fetch.json 2> $O/pmc_fetch.err
