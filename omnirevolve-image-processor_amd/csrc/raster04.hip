@@ -649,8 +649,8 @@ static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F) {
     HIPC(c, hipMemsetAsync(A.winfo + 2 * (size_t)b0, 0, (size_t)2 * Ml * sizeof(WalkInfo), LN(c).stream));
     HIPC(c, hipMemsetAsync(d_over, 0, 4, LN(c).stream));
     if (getenv("ORIP_WALK_DBG")) {          // per-component counters (walks, steps, memo hits, closed cycles, tile loads, size)
-        HIPC(c, LN(c).vtmp[11].ensure((size_t)NCl * 128 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[11].p, 0, (size_t)NCl * 128, LN(c).stream));
-        A.dbg = LN(c).vtmp[11].as<unsigned long long>() - 16ull * c0;
+        HIPC(c, LN(c).vtmp[11].ensure((size_t)NCl * 256 + 64)); HIPC(c, hipMemsetAsync(LN(c).vtmp[11].p, 0, (size_t)NCl * 256, LN(c).stream));
+        A.dbg = LN(c).vtmp[11].as<unsigned long long>() - 32ull * c0;
     }
     { ProfScope ps(c, "k_trace"); hipLaunchKernelGGL(k_trace, dim3(NCl), dim3(64), 0, LN(c).stream, A); }
     HIPC(c, hipGetLastError());
@@ -708,17 +708,17 @@ static int trace_finish(orip_ctx* c, Prep04& R, int layer) {
     }
     if (getenv("ORIP_WALK_DBG")) {
         const unsigned NCl = c1 - c0;
-        std::vector<unsigned long long> h((size_t)NCl * 16);
+        std::vector<unsigned long long> h((size_t)NCl * 32);
         HIPC(c, hipMemcpy(h.data(), LN(c).vtmp[11].p, h.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long tot[16] = {0}; size_t big = 0;
-        for (size_t i = 0; i < h.size(); i++) tot[i % 16] += h[i];
-        for (size_t i = 0; i < NCl; i++) if (h[i * 16 + 7] > h[big * 16 + 7]) big = i;
-        const unsigned long long* d = &h[big * 16];
+        unsigned long long tot[32] = {0}; size_t big = 0;
+        for (size_t i = 0; i < h.size(); i++) tot[i % 32] += h[i];
+        for (size_t i = 0; i < NCl; i++) if (h[i * 32 + 7] > h[big * 32 + 7]) big = i;
+        const unsigned long long* d = &h[big * 32];
         fprintf(stderr, "[walk dbg] layer %d NC=%u M=%u F=%u: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu | largest fg=%llu: w1=%llu s1=%llu w2=%llu s2=%llu hit=%llu det=%llu tiles=%llu jumped=%llu\n",
                 layer, NCl, Ml, R.F[layer], tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[15]);
         if (d[8]) fprintf(stderr, "[walk prof] layer %d largest component: cycles total=%llu window loads=%llu scans=%llu look-ups=%llu | look-ups=%llu loop exits=%llu\n",
                           layer, d[8], d[9], d[10], d[11], d[12], d[13]);
-        if (d[8]) fprintf(stderr, "[walk prof]   inside the look-ups: duplicate check %llu cycles\n", d[14]);
+        if (d[8]) fprintf(stderr, "[walk prof]   inside the look-ups: duplicate check %llu cycles (exact check in %llu look-ups); forced stretches %llu cycles in %llu calls, %llu rounds; stepping loop %llu cycles; walk start + end %llu cycles\n", d[14], d[20], d[16], d[17], d[18], d[19], d[21]);
     }
     const unsigned long long h_pts = h_tot.pts; const unsigned h_paths = h_tot.paths, h_own = h_tot.own, h_pieces = h_tot.pieces;
     // ---- the contours of the layer in walk-coded form (walker.h): nothing is expanded here

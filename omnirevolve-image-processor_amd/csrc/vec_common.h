@@ -181,13 +181,26 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                 arc += (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
             };
             auto pred = [&](int64_t k) -> int64_t { return k == 0 ? (closed_arc ? n - 1 : 0) : k - 1; };
-            int64_t k = tid;
-            for (; k + 768 < n; k += 1024) {
-                const int2 a0 = P2(k), a1 = P2(k + 256), a2 = P2(k + 512), a3 = P2(k + 768);
-                const int2 b0 = P2(pred(k)), b1 = P2(k + 255), b2 = P2(k + 511), b3 = P2(k + 767);
-                seg(k, a0, b0); seg(k + 256, a1, b1); seg(k + 512, a2, b2); seg(k + 768, a3, b3);
+            // A wave takes four consecutive windows of 64 points per turn and fetches every point once (a cursor call is ~25 instructions):
+            // the predecessor of point k sits in the lane below, that of a window's first point in the last lane of the window before,
+            // and only the first point of a turn needs one extra fetch.
+            const int lane = tid & 63;
+            for (int64_t base = (int64_t)(tid >> 6) * 256; base < n; base += 1024) {
+                int2 p[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k < n ? P2(k) : make_int2(0, 0); }
+                int2 first = P2(pred(base));
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    int2 b;
+                    b.x = __builtin_amdgcn_update_dpp(0, p[w].x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                    b.y = __builtin_amdgcn_update_dpp(0, p[w].y, 0x138, 0xf, 0xf, true);
+                    if (lane == 0) b = first;
+                    const int64_t k = base + 64 * w + lane;
+                    if (k < n) seg(k, p[w], b);
+                    first = make_int2(__builtin_amdgcn_readlane(p[w].x, 63), __builtin_amdgcn_readlane(p[w].y, 63));
+                }
             }
-            for (; k < n; k += 256) seg(k, P2(k), P2(pred(k)));
         } else if (!any_per) {
             // bounding box only: four independent 8-byte loads per turn keep the memory pipeline busy (the loop is latency-bound otherwise)
             int64_t k = tid;

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict
 }
 
 // ================================================================= A2: resample (08:53-64)
-#define ORIP_LONG_CUM 128      // polylines above this many points get a wavefront for their cumulative lengths (k_cumlen_long)
+#define ORIP_LONG_CUM 128      // polylines above this many points get a wavefront for their cumulative lengths (k_cumlen_long2)
 struct RsInfo { int64_t n_eff; double total; unsigned m; unsigned pass; };
-// sequential float32 cumsum per polyline (np.cumsum): one lane per short polyline; long polylines (k_cumlen_long) use one
+// sequential float32 cumsum per polyline (np.cumsum): one lane per short polyline; long polylines (k_cumlen_long2) use one
 // wavefront: 64 segment lengths are computed / loaded by the lanes, the strictly sequential chain of float adds then runs
 // over them with v_readlane (the order of additions, and therefore every rounding, is the reference's)
 __device__ __forceinline__ void rs_finish(RsInfo& r, float acc, int64_t n, double step) {
@@ -139,53 +139,6 @@ __device__ __forceinline__ float cum_window(float dval, int lane, unsigned& E, u
     return __uint_as_float(out);
 }
 __device__ __forceinline__ float cum_state_value(unsigned E, unsigned M) { return __uint_as_float((E << 23) | (M & 0x7fffffu)); }
-template <class Src, bool CHAIN>
-__global__ __launch_bounds__(64) void k_cumlen_long(Src src, int64_t n_polys, double step, float* __restrict__ cum, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
-    const int lane = threadIdx.x;
-    for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
-        const int64_t i = ord[rr];                 // longest perimeter first: the long chains start at once, the short ones fill in behind
-        RsInfo r = info[i];
-        const int64_t n = r.n_eff;
-        if (n <= ORIP_LONG_CUM) continue;
-        auto cu = src.cur(i); float* s = cum + src.off[i];
-        const int64_t nseg = n - 1;
-        float acc = 0.f; unsigned cE = 0u, cM = 0u;
-        if (lane == 0) s[0] = 0.f;
-        // four windows of 64 segment lengths per turn.  The POINTS of the next turn are requested before the serial chain of this one
-        // runs and are only turned into lengths after it (using them earlier would make the chain wait for the loads after all).
-        auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4]) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; const bool in = k < nseg; a[w] = in ? cu.at(k) : make_int2(0, 0); b2[w] = in ? cu.at(k + 1) : make_int2(0, 0); }
-        };
-        auto lengths = [&](const int2 (&a)[4], const int2 (&b2)[4], float (&sl)[4]) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) { float dx = (float)b2[w].x - (float)a[w].x, dy = (float)b2[w].y - (float)a[w].y; float qx = dx * dx, qy = dy * dy; sl[w] = sqrtf(qx + qy); }   // seg_len_f32; padding: 0
-        };
-        int2 ra[4], rb[4]; float cur[4];
-        request(0, ra, rb); lengths(ra, rb, cur);
-        for (int64_t base = 0; base < nseg; base += 256) {
-            request(base + 256, ra, rb);
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int64_t k = base + 64 * w + lane;
-                float pre;
-                if (CHAIN) {
-                    // the strictly sequential float chain p[j] = p[j-1] + d[j] as 63 wave-shifted adds: after step j lane j is final, and a
-                    // final lane recomputes the same sum from its final neighbour at every later step (lane 0 reads 0 and keeps 0 + d'[0])
-                    float d = (lane == 0) ? __fadd_rn(acc, cur[w]) : cur[w];      // acc starts at +0: 0 + s0 == s0 exactly, as the reference's first element
-                    pre = d;
-#pragma unroll
-                    for (int j = 1; j < 64; j++)
-                        pre = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pre), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), d);
-                    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre), 63));      // padding lanes add +0: lane 63 holds the last real sum
-                } else { pre = cum_window(cur[w], lane, cE, cM); acc = cum_state_value(cE, cM); }
-                if (k < nseg) s[k + 1] = pre;
-            }
-            lengths(ra, rb, cur);
-        }
-        if (lane == 0) { rs_finish(r, acc, n, step); info[i] = r; }
-    }
-}
 // ---- both reading directions of every polyline in one launch (prefetch08): the reversed polyline has the same segment lengths in
 // reverse order, and its float32 running sum is a second, independent serial chain -- two chains interleave in one wavefront for the
 // price of one (a dependent add waits ~10 cycles for its predecessor anyway).  Forward = the polyline as split_small keeps it (opened
@@ -224,60 +177,67 @@ __global__ __launch_bounds__(128) void k_cumlen2(Src src, const PolyFeat* __rest
         info[dir ? n_polys + i : i] = r;
     }
 }
+// lane j <- lane j + 1 of v; lane 63 <- `last` (the successor of a window's last point is the first point of the next window)
+__device__ __forceinline__ int2 lane_succ(const int2 v, const int2 last, int lane) {
+    int2 r;
+    r.x = __builtin_amdgcn_update_dpp(0, v.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    r.y = __builtin_amdgcn_update_dpp(0, v.y, 0x130, 0xf, 0xf, true);
+    if (lane == 63) r = last;
+    return r;
+}
 template <class Src, bool CHAIN>
 __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
     const int lane = threadIdx.x;
+    const bool rev = blockIdx.y == 1;      // blockIdx.y picks the reading direction: one wave per polyline and direction
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = ord[rr];
-        RsInfo rf = info[i], rb = info[n_polys + i];
-        // blockIdx.y picks the reading direction: two dependent chains interleaved in one wave cost their sum, two waves run side by side
-        const bool do_f = blockIdx.y == 0 && rf.n_eff > ORIP_LONG_CUM, do_b = blockIdx.y == 1 && rb.n_eff > ORIP_LONG_CUM;
-        if (!do_f && !do_b) continue;
+        RsInfo r = info[rev ? n_polys + i : i];
+        if (r.n_eff <= ORIP_LONG_CUM) continue;
         auto cu = src.cur(i); const int64_t nfull = src.len(i);
-        float* sf = cum + src.off[i]; float* sb = cum + rev_off + src.off[i];
-        const int64_t nsf = do_f ? rf.n_eff - 1 : 0, nsb = do_b ? rb.n_eff - 1 : 0, nsm = nsf > nsb ? nsf : nsb;
-        float accf = 0.f, accb = 0.f; unsigned cE = 0u, cM = 0u;
-        if (lane == 0) { if (do_f) sf[0] = 0.f; if (do_b) sb[0] = 0.f; }
-        // per turn: 4 windows of 64 segment lengths in each direction; the points of the next turn are requested before this turn's chains run
-        auto request = [&](int64_t base, int2 (&a)[4], int2 (&b2)[4], int2 (&c2)[4], int2 (&d2)[4]) {
+        float* s = cum + (rev ? rev_off : 0) + src.off[i];
+        const int64_t ns = r.n_eff - 1;                                             // segments; points 0 .. ns of this reading
+        float acc = 0.f; unsigned cE = 0u, cM = 0u;
+        if (lane == 0) s[0] = 0.f;
+        // A turn is 4 windows of 64 segment lengths.  Every point is fetched ONCE (the cursor call is ~25 instructions, and the launch is bound by
+        // instruction issue: 2.8e8 points per heavy layer and direction): the far end of segment k is the point in the next lane, the far end of a
+        // window's last segment the first point of the next window, of a turn's last segment one extra point.  The points of the next turn are
+        // requested before this turn's sums run.
+        auto P = [&](int64_t k) { return cu.at(rev ? nfull - 1 - k : k); };
+        auto request = [&](int64_t base, int2 (&p)[5]) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k <= ns ? P(k) : make_int2(0, 0); }
+            p[4] = base + 256 <= ns ? P(base + 256) : make_int2(0, 0);
+        };
+        auto lengths = [&](int64_t base, const int2 (&p)[5], float (&sl)[4]) {
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const int64_t k = base + 64 * w + lane;
-                const bool inf = k < nsf, inb = k < nsb;
-                a[w] = inf ? cu.at(k) : make_int2(0, 0); b2[w] = inf ? cu.at(k + 1) : make_int2(0, 0);
-                c2[w] = inb ? cu.at(nfull - 1 - k) : make_int2(0, 0); d2[w] = inb ? cu.at(nfull - 2 - k) : make_int2(0, 0);
+                const int2 nx0 = w < 3 ? make_int2(__builtin_amdgcn_readlane(p[w + 1].x, 0), __builtin_amdgcn_readlane(p[w + 1].y, 0)) : p[4];
+                const int2 b2 = lane_succ(p[w], nx0, lane);
+                float dx = (float)b2.x - (float)p[w].x, dy = (float)b2.y - (float)p[w].y; float qx = dx * dx, qy = dy * dy;
+                sl[w] = (base + 64 * w + lane < ns) ? sqrtf(qx + qy) : 0.f;            // seg_len_f32; beyond the last segment: +0
             }
         };
-        auto lengths = [&](const int2 (&a)[4], const int2 (&b2)[4], float (&sl)[4]) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) { float dx = (float)b2[w].x - (float)a[w].x, dy = (float)b2[w].y - (float)a[w].y; float qx = dx * dx, qy = dy * dy; sl[w] = sqrtf(qx + qy); }
-        };
-        int2 ra[4], rb2[4], rc[4], rd[4]; float curf[4], curb[4];
-        request(0, ra, rb2, rc, rd); lengths(ra, rb2, curf); lengths(rc, rd, curb);
-        for (int64_t base = 0; base < nsm; base += 256) {
-            request(base + 256, ra, rb2, rc, rd);
+        int2 rp[5]; float cur[4];
+        request(0, rp); lengths(0, rp, cur);
+        for (int64_t base = 0; base < ns; base += 256) {
+            request(base + 256, rp);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
-                // ONE direction per wave (the one this block was given)
-                const float cv = do_f ? curf[w] : curb[w];
-                float pv, last;
+                float pv;
                 if (CHAIN) {                                          // the strictly sequential float sums as 63 wave-shifted adds
-                    float dv = (lane == 0) ? __fadd_rn(do_f ? accf : accb, cv) : cv;
+                    float dv = (lane == 0) ? __fadd_rn(acc, cur[w]) : cur[w];
                     pv = dv;
 #pragma unroll
                     for (int j = 1; j < 64; j++)
                         pv = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pv), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)), dv);
-                    last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 63));
-                } else { pv = cum_window(cv, lane, cE, cM); last = cum_state_value(cE, cM); }
-                if (do_f) { accf = last; if (k < nsf) sf[k + 1] = pv; } else { accb = last; if (k < nsb) sb[k + 1] = pv; }
+                    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), 63));
+                } else { pv = cum_window(cur[w], lane, cE, cM); acc = cum_state_value(cE, cM); }
+                if (k < ns) s[k + 1] = pv;
             }
-            lengths(ra, rb2, curf); lengths(rc, rd, curb);
+            lengths(base + 256, rp, cur);
         }
-        if (lane == 0) {
-            if (do_f) { rs_finish(rf, accf, rf.n_eff, step); info[i] = rf; }
-            if (do_b) { rs_finish(rb, accb, rb.n_eff, step); info[n_polys + i] = rb; }
-        }
+        if (lane == 0) { rs_finish(r, acc, r.n_eff, step); info[rev ? n_polys + i : i] = r; }
     }
 }
 // any_out: set when a sampled polyline reaches beyond the canvas (its samples lie inside the box of its points): only then can a sample be
@@ -453,7 +413,7 @@ __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sb
 // decided by exact arithmetic; the reference decides them with a float64 running sum whose roundings depend on the whole history of pushes
 // and pops.  Given the heads, that history is a fixed list of operations (+d[j], then -d[h] for every popped h), and its value after every
 // operation is a prefix sum with SEQUENTIAL rounding -- which 64 lanes evaluate as 63 wave-shifted adds (lane i is final after step i,
-// exactly as k_cumlen_long does for float32).  So a wavefront replays 64 operations at a time instead of deciding one comparison per
+// exactly as k_cumlen_long2 could for float32).  So a wavefront replays 64 operations at a time instead of deciding one comparison per
 // ~400 cycles, then checks the predicted heads against the reference's loop conditions with the running values it now has (after the last
 // pop: not > T; before it: > T).  Samples up to the first one that fails the check are final; that one is decided by the plain loop, and
 // the replay goes on from there with heads that can only have moved forward (running maximum).  Whatever the prediction was, a sample
@@ -1530,8 +1490,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
         if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
             ORIP_WITH_SRC(c, kept0.p, sv, {
-                if (chain) hipLaunchKernelGGL((k_cumlen_long<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord);
-                else hipLaunchKernelGGL((k_cumlen_long<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192)), dim3(64), 0, LN(c).stream, sv, nk, step, cum, info, ord); }); }
+                if (chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord);
+                else hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord); }); }
         }
         tick("cumlen");
         HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));

@@ -78,7 +78,7 @@ struct WalkArgs {
     const unsigned long long* pts_off; const unsigned* path_off;   // exclusive scans over winfo (len_kept, kept)
     unsigned long long layer_pts_base[ORIP_MAX_LAYERS]; unsigned layer_path_base[ORIP_MAX_LAYERS];
     int32_t* pts[ORIP_MAX_LAYERS]; int64_t* off[ORIP_MAX_LAYERS];
-    unsigned long long* dbg;           // optional counters, 16 per component
+    unsigned long long* dbg;           // optional counters, 32 per component
 };
 
 #ifndef ORIP_WALK_LEAD
@@ -146,10 +146,13 @@ struct Wave {
     unsigned codes_done, marks_done;    // steps of the walk whose code / visited mark has left the wave
     u8* st; int W, H;
     unsigned long long t_tile = 0;
+    mutable unsigned long long n_exact = 0;
+    u8* dtab;                   // [8192]: scratch of dup_distance's pre-check
     __device__ Wave() : lane((int)(threadIdx.x & 63)), tx0(0), ty0(0), have(false), nload(0), pl(0), li(0), reload(true), lastk(8), noff(0), noffa(0), dplv(0), sel(0), thr(-64),
                         va(0), v(0), rec(0), home(~0u), codes_done(0), marks_done(0), st(nullptr), W(0), H(0) {
         __shared__ u8 lds_tile[WT * WTP];
-        tile = lds_tile; lds_base = (unsigned)(uintptr_t)lds_tile;
+        __shared__ u8 lds_dup[8192];
+        tile = lds_tile; lds_base = (unsigned)(uintptr_t)lds_tile; dtab = lds_dup;
     }
     __device__ void init(u8* st_, int W_, int H_) {
         st = st_; W = W_; H = H_;
@@ -322,6 +325,19 @@ struct Wave {
         if (cell & WB_RING) { reload = true; place(steps); return 1; }
         return 0;
     }
+    // The cursor stands on a flagged pixel of a listed chain.  If it got there along the chain (the cell it came from carries ST_CHAIN) and
+    // no other neighbour does, it is leaving through an end pixel: nothing lies ahead, and the caller saves the three memory round trips
+    // it would take to find that out from the chain list.  (A neighbour ahead with ST_CHAIN: an interior pixel that carries the stale
+    // start flag of an earlier walk -- a jump from there is as good as one from an end.)  Not decidable on the window ring: false.
+    __device__ bool came_along_chain() const {
+        if (reload || lastk >= 8) return false;
+        const u8 cell = tile[li];
+        if (cell & WB_RING) return false;
+        const u8 nbv = lane < 8 ? tile[li + noff] : (u8)0;
+        const unsigned chain_nb = (unsigned)__ballot((nbv & ST_FG) && (nbv & ST_CHAIN)) & 0xffu;
+        const unsigned back = 0x80u >> lastk;                          // NEIGH8 index 7 - lastk: where the cursor came from
+        return (chain_nb & back) != 0u && (chain_nb & ~back) == 0u;
+    }
     // the stepping loop may pass the flagged cell the cursor stands on (this window only: a reloaded window carries the flag again)
     __device__ void unflag_cursor(unsigned steps) {
         if (reload) place(steps);
@@ -335,7 +351,20 @@ struct Wave {
     __device__ int first(bool pred) const { unsigned long long m = __ballot(pred); return m ? __ffsll((long long)m) - 1 : -1; }
     // key: this lane's pending state + 1 (0: none).  Smallest d in [1, n) with key(lane - d) == key(lane), 0 if there is none: the keys
     // slide down the wave one lane per round (DPP wave_shr:1, zeros come in at lane 0), four rounds per loop trip; no LDS, no branches.
+    // Two pending states of one look-up are almost never equal (a cycle shorter than the batch), and the exact search costs n rounds of a
+    // lone wave (4.3 of 57 M cycles of the largest component of the bench image): every lane first drops its lane
+    // number into a hashed LDS byte and reads it back -- a lane that finds its own number in every case has no equal (and no colliding)
+    // partner, and only a look-up where some lane does not runs the exact rounds.  The table is never cleared: a lane reads what the
+    // lanes of THIS look-up wrote last.
     __device__ unsigned dup_distance(unsigned key, unsigned n) const {
+        if (n > 2u) {
+            const unsigned slot = (key * 2654435761u) >> 19;
+            if (key != 0u) dtab[slot] = (u8)lane;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const bool clash = key != 0u && dtab[slot] != (u8)lane;
+            if (!__ballot(clash)) return 0u;
+        }
+        n_exact++;
         unsigned t = key, best = ~0u;
         for (unsigned d = 1; d < n; d += 4) {
 #pragma unroll
@@ -350,14 +379,25 @@ struct Wave {
     // next q in [q0, e) whose pixel satisfies: (state & need) == need && !(state & ST_VIS).  The scans of a component move forward through its
     // pixel list in small steps, so the list entries are kept 64 at a time in a VGPR (lin_blk = entries [lin_q0, lin_q0 + 64)): a scan then costs
     // one memory round trip (the state bytes) instead of two dependent ones.
-    unsigned lin_blk = 0, lin_q0 = ~0u;
+    // The hit's pixel and state byte come out of the lanes' registers (scan_lin, scan_st): the walk that starts there needs both, and
+    // fetching them again would be two more dependent round trips per walk.  The block after the current one is requested when a block
+    // is entered (its latency ends behind whatever the walks in between wait for).
+    unsigned lin_blk = 0, lin_q0 = ~0u, lin_nxt = 0, lin_nq0 = ~0u, scan_lin = 0; u8 scan_st = 0;
     __device__ unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) {
         for (unsigned q = q0; q < e; ) {
-            if (q < lin_q0 || q >= lin_q0 + 64u) { lin_q0 = q; lin_blk = (q + (unsigned)lane < e) ? lin[q + lane] : 0u; }
-            const unsigned qq = lin_q0 + (unsigned)lane; bool ok = false;
-            if (qq >= q && qq < e) { u8 x = ld_state(lin_blk); ok = ((x & need) == need) && !(x & ST_VIS); }
+            if (q < lin_q0 || q >= lin_q0 + 64u) {
+                if (q == lin_nq0) lin_blk = lin_nxt; else lin_blk = (q + (unsigned)lane < e) ? lin[q + lane] : 0u;
+                lin_q0 = q;
+                lin_nq0 = q + 64u; lin_nxt = (lin_nq0 + (unsigned)lane < e) ? lin[lin_nq0 + lane] : 0u;
+            }
+            const unsigned qq = lin_q0 + (unsigned)lane; bool ok = false; u8 x = 0;
+            if (qq >= q && qq < e) { x = ld_state(lin_blk); ok = ((x & need) == need) && !(x & ST_VIS); }
             unsigned long long m = __ballot(ok);
-            if (m) return lin_q0 + (unsigned)(__ffsll((long long)m) - 1);
+            if (m) {
+                const int hl = __ffsll((long long)m) - 1;
+                scan_lin = (unsigned)__builtin_amdgcn_readlane((int)lin_blk, hl); scan_st = (u8)__builtin_amdgcn_readlane((int)x, hl);
+                return lin_q0 + (unsigned)hl;
+            }
             q = lin_q0 + 64u;
         }
         return e;
@@ -471,7 +511,7 @@ struct Wave {
 };
 #else
 struct Wave {
-    u8 nv[8]; unsigned nload = 0; unsigned long long t_tile = 0;
+    u8 nv[8]; unsigned nload = 0; unsigned long long t_tile = 0, n_exact = 0;
     unsigned pl = 0, home = ~0u;
     unsigned pend_state = 0;
     u8* st = nullptr; int W = 0, H = 0;
@@ -532,8 +572,9 @@ struct Wave {
     unsigned bcast(unsigned v, int) const { return v; }
     int first(bool pred) const { return pred ? 0 : -1; }
     unsigned dup_distance(unsigned, unsigned) const { return 0u; }       // one pending state at most
-    unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) const {
-        for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) return q; }
+    unsigned scan_lin = 0; u8 scan_st = 0;
+    unsigned scan(const unsigned* lin, unsigned q0, unsigned e, u8 need) {
+        for (unsigned q = q0; q < e; q++) { u8 v = st[lin[q]]; if (((v & need) == need) && !(v & ST_VIS)) { scan_lin = lin[q]; scan_st = v; return q; } }
         return e;
     }
     void scan2(int dx, int dy, int& ox, int& oy, int& tx, int& ty) const { ox = dx; oy = dy; tx = dx; ty = dy; }
@@ -600,7 +641,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     unsigned logcur = 0, stepcur = 0;
     bool over = false, stalled = false;
     unsigned long long d_w1 = 0, d_s1 = 0, d_w2 = 0, d_s2 = 0, d_hit = 0, d_det = 0, d_jump = 0;
-    unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0, t_f3 = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
+    unsigned long long t_scan = 0, t_flush = 0, n_flush = 0, n_ev = 0, t_f3 = 0, t_chain = 0, n_chain = 0, n_round = 0, t_run = 0, t_walk = 0; const unsigned long long t_begin = WPROF_NOW();   // ORIP_WALK_PROF builds only
     auto finish = [&](unsigned slot, unsigned long long len, unsigned n_own, unsigned sbeg, unsigned log_i1, unsigned R, unsigned flags) {
         if (wv.leader()) { WalkInfo wi; wi.len_kept = len >= 5 ? (unsigned)len : 0u; wi.n_own = n_own; wi.step_begin = sbeg; wi.log_i1 = log_i1; wi.R = R; wi.flags = flags; A.winfo[slot] = wi; }
     };
@@ -608,7 +649,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     // ---- phase 1: walks from endpoints (04:144-171); >= 2 points to be a path (04:168), >= 5 to survive vectorize_layer (04:224)
     const unsigned long long g1 = (unsigned long long)(total_fg * 2);
     for (unsigned q = tscan(b, ST_FG | ST_END); q < e; q = tscan(q + 1, ST_FG | ST_END)) {
-        unsigned s = A.lin[q];
+        unsigned s = wv.scan_lin;
         wv.set_cursor(s);
         const unsigned sbeg = step_base + stepcur;
         u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
@@ -644,12 +685,13 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
     const unsigned g2 = fg * 4u;                                  // guard of a leftover walk (04:199)
     const unsigned nbatch0 = wv.nl() < ORIP_WALK_BATCH ? wv.nl() : ORIP_WALK_BATCH;
     for (unsigned q = tscan(b, ST_FG); q < e && !over && !stalled; q = tscan(q + 1, ST_FG)) {
-        unsigned s = A.lin[q];
+        const unsigned long long t_w0 = WPROF_NOW();
+        unsigned s = wv.scan_lin;
         wv.set_cursor(s);
         const unsigned sbeg = step_base + stepcur;
         u8* slog = A.steplog + (size_t)sbeg; const unsigned room = step_cap - stepcur;
         wv.begin_walk(s);
-        { u8 sv = wv.ld_state(s); wv.mark_cursor(sv); }
+        wv.mark_cursor(wv.scan_st);
         d_w2++;
         Hot h; h.steps = 0;                   // steps taken = own points - 1 = value of the reference's guard counter at its check
         h.limit = 0; h.nb = 0;                // pending no-fresh states: those of the last nb steps
@@ -724,7 +766,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         // Leaves the cursor on the last pixel taken; the window is re-placed from the state plane.  Returns `ended` (0: walk goes on).
         unsigned last_jump_end = ~0u;
         auto chain_jump = [&]() -> int {
-            if (!A.cref || wv.pl == last_jump_end || wv.lastk >= 8) { wv.unflag_cursor(h.steps); return 0; }
+            if (!A.cref || wv.pl == last_jump_end || wv.lastk >= 8 || wv.came_along_chain()) { wv.unflag_cursor(h.steps); return 0; }
             const unsigned lane = wv.l0();
             wv.flush_codes(slog, room, h.steps);                          // the records of the steps so far leave the wave: codes, and the visited
             wv.fence();                                                   // marks the state bytes read below must already show
@@ -784,7 +826,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
                         if (res) break;
                     }
                 }
-                d_jump += (unsigned)r;
+                d_jump += (unsigned)r; n_round++;
                 wv.pl = wv.bcast(q, r - 1); wv.lastk = (int)wv.bcast((unsigned)k, r - 1); h.allow = 0xffu & ~(0x80u >> wv.lastk);
                 idx = (unsigned)((int)idx + dir * r);
                 if (!go_on) break;
@@ -796,18 +838,21 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             return res;
         };
 #endif
+        WPROF_ADD(t_walk, t_w0);
         while (true) {
             if (h.steps >= room) { over = true; break; }
             unsigned lim = (h.steps & ~63u) + 64u;                    // the records of 64 steps fit the lanes: codes and marks leave at every multiple of 64
             if (lim > g2 + 1u) lim = g2 + 1u;
             if (lim > room) lim = room;
             h.limit = lim;
+            const unsigned long long t_r0 = WPROF_NOW();
             int ev = wv.run(h, slog, room);
+            WPROF_ADD(t_run, t_r0);
             n_ev++;
             if (ev == EV_DEAD) {
                 int f = wv.resume_flagged(h.steps);                   // GPU: a flagged window cell stops the loop the same way
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (f == 3) { ended = chain_jump(); if (ended) break; f = 1; }       // end pixel of a listed chain: the forced stretch ahead in one go (or not: then the flag is out of the way)
+                if (f == 3) { const unsigned long long t_0 = WPROF_NOW(); n_chain++; ended = chain_jump(); WPROF_ADD(t_chain, t_0); if (ended) break; f = 1; }       // end pixel of a listed chain: the forced stretch ahead in one go (or not: then the flag is out of the way)
 #endif
                 if (f == 1) {                                         // window re-placed (or a stale flag cleared): go on
                     if (h.steps == stall_steps && ++stall > 8u) { stalled = true; break; }     // ... unless nothing moves: a bug, never a hang
@@ -828,6 +873,7 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
             ended = flush(); if (ended) break;
             h.nbatch = h.nbatch * 2u < wv.nl() ? h.nbatch * 2u : wv.nl();
         }
+        const unsigned long long t_w1 = WPROF_NOW();
         if (!ended && h.nb > drop) ended = flush();
         wv.flush_codes(slog, room, h.steps);
         if (ended != 1) discard_run();                                // a run that never reached a known trajectory stays out of the memo
@@ -840,13 +886,14 @@ ORIP_HD inline void trace_component(const WalkArgs& A, unsigned c) {
         if (ended == 1) flags = 2;                                    // the end point lies in the recorded trajectory: walk_close_tail decides about the closing point
         else if (len >= 2 && close_to(W, s, wv.pl)) { flags = 1; len++; }
         finish(2u * b + fg + (q - b), len >= 2 ? len : 0, steps, sbeg, tail_i1, tail_R, flags);
+        WPROF_ADD(t_walk, t_w1);
     }
     if (A.log_used && wv.leader()) A.log_used[c] = logcur;
     if (over && wv.leader()) *A.overflow = 1;
     if (stalled && wv.leader()) *A.overflow = 2;                   // internal error: the host reports it instead of retrying
     if (A.dbg && wv.leader()) {
-        unsigned long long* d = A.dbg + 16ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
-        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3; d[15] = d_jump;     // cycle counts: ORIP_WALK_PROF builds only
+        unsigned long long* d = A.dbg + 32ull * c; d[0] = d_w1; d[1] = d_s1; d[2] = d_w2; d[3] = d_s2; d[4] = d_hit; d[5] = d_det; d[6] = wv.nload; d[7] = (unsigned long long)fg;
+        d[8] = WPROF_NOW() - t_begin; d[9] = wv.t_tile; d[10] = t_scan; d[11] = t_flush; d[12] = n_flush; d[13] = n_ev; d[14] = t_f3; d[15] = d_jump; d[16] = t_chain; d[17] = n_chain; d[18] = n_round; d[19] = t_run; d[20] = wv.n_exact; d[21] = t_walk;     // cycle counts: ORIP_WALK_PROF builds only
     }
 }
 
