@@ -832,11 +832,19 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
             const unsigned mink = (unsigned)__builtin_amdgcn_readlane((int)m, 63);
             bool final_ = x0 == 0 && y0 == 0 && x1 == Gm1 && y1 == Gm1;            // everything scanned
             if (!final_ && mink != ~0u) {
-                int gap = 0x7fff;                                                    // distance to the nearest unscanned cell, over the open sides
-                if (x0 > 0) gap = min(gap, cx - (x0 << sh) + 1);
-                if (x1 < Gm1) gap = min(gap, ((x1 + 1) << sh) - cx);
-                if (y0 > 0) gap = min(gap, cy - (y0 << sh) + 1);
-                if (y1 < Gm1) gap = min(gap, ((y1 + 1) << sh) - cy);
+                int gap;                                                             // distance to the nearest unscanned cell, over the open sides
+                if (r == 1) {
+                    // the 3x3 window (94 % of the rounds): its sides lie one cell beyond the cursor's cell, so the gap is a function of the cursor's
+                    // position inside its cell.  A side on the border of the grid counts as open here -- a smaller gap is conservative.
+                    const int cell = 1 << sh, lx = cx & (cell - 1), ly = cy & (cell - 1);
+                    gap = cell + min(min(lx + 1, cell - lx), min(ly + 1, cell - ly));
+                } else {
+                    gap = 0x7fff;
+                    if (x0 > 0) gap = min(gap, cx - (x0 << sh) + 1);
+                    if (x1 < Gm1) gap = min(gap, ((x1 + 1) << sh) - cx);
+                    if (y0 > 0) gap = min(gap, cy - (y0 << sh) + 1);
+                    if (y1 < Gm1) gap = min(gap, ((y1 + 1) << sh) - cy);
+                }
                 const unsigned g2 = (unsigned)(gap * gap);                           // gap < 2^15: exact
                 const unsigned bfl = (unsigned)NNU((unsigned)__uint_as_float(mink)); // floor of the best squared distance (< 2^31)
                 final_ = bfl + 1u <= g2 - (g2 >> 18) - 1u && g2 > 1u;
@@ -848,23 +856,25 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
                     for (int o = 32; o > 0; o >>= 1) { const unsigned t_ = (unsigned)__shfl_xor((int)ci2, o, 64); ci2 = t_ < ci2 ? t_ : ci2; }
                     tie = __ballot(myk == mink && myi == ci2);
                 }
+                // every lane settles the reading direction and the next cursor of ITS candidate (a dozen vector instructions); the winner's come
+                // out with two v_readlane -- instead of three, followed by the same arithmetic on scalars that wait for them
+                const unsigned sxy = my0 & 0x7fff7fffu;
+                const float ds = nn_d2((int)(sxy & 0xffffu), (int)(sxy >> 16), cx, cy), de = nn_d2((int)(my1 & 0xffffu), (int)(my1 >> 16), cx, cy);
+                const bool cl = (my0 & 0x80000000u) != 0;
+                const bool flip = cl ? false : !(ds <= de);
+                const unsigned ncur = (cl || flip) ? sxy : my1;
+                const unsigned pack = (myi << 1) | (flip ? 1u : 0u);
                 const int win_lane = __ffsll((long long)tie) - 1;
-                wi = (unsigned)__builtin_amdgcn_readlane((int)myi, win_lane);
+                wi = (unsigned)__builtin_amdgcn_readlane((int)pack, win_lane);
+                w1 = (unsigned)__builtin_amdgcn_readlane((int)ncur, win_lane);
                 w0 = (unsigned)__builtin_amdgcn_readlane((int)my0, win_lane);
-                w1 = (unsigned)__builtin_amdgcn_readlane((int)my1, win_lane);
                 break;
             }
         }
-        const int bi = (int)wi;
-        const int sx = (int)(w0 & 0x7fffu), sy = (int)((w0 >> 16) & 0x7fffu), ex = (int)(w1 & 0xffffu), ey = (int)(w1 >> 16);
-        const float ds = nn_d2(sx, sy, cx, cy), de = nn_d2(ex, ey, cx, cy);
-        const bool cl = (w0 & 0x80000000u) != 0;
-        const bool flip = cl ? false : !(ds <= de);
-        const int fl = NNU(flip ? 1 : 0);
-        if (lane == 0) P[bi].x = w0 | 0x8000u;                       // the used flag, through the type the entries are read as (lane 0 is the only writer)
-        ringv = lane == (step & 63) ? (unsigned)((bi << 1) | fl) : ringv;
+        P[wi >> 1].x = w0 | 0x8000u;                                 // the used flag, through the type the entries are read as (every lane writes the same word)
+        ringv = lane == (step & 63) ? wi : ringv;
         if ((step & 63) == 63) { order[step - 63 + lane] = (int32_t)(ringv >> 1); flips[step - 63 + lane] = (uint8_t)(ringv & 1u); }
-        if (cl || fl) { cx = sx; cy = sy; } else { cx = ex; cy = ey; }
+        cx = (int)(w1 & 0xffffu); cy = (int)(w1 >> 16);
     }
     { const int done = n & ~63; if (done + lane < n) { order[done + lane] = (int32_t)(ringv >> 1); flips[done + lane] = (uint8_t)(ringv & 1u); } }
 #undef NNU
