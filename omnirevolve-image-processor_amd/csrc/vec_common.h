@@ -718,6 +718,355 @@ __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restri
     e[i] = q;
 }
 
+// ---- the common step of k_greedy_nn_fast as ONE asm statement that runs step after step (r03).
+// The compiled step is ~260 instructions on its usual path and stalls a dozen times on scalar instructions that consume vector results (cell
+// ranges read out lane by lane, the gap test, the winner's end points): 1 750 cycles.  The usual path is narrow -- the 3x3 window away from the
+// first / last cell row, 1..128 candidates, a unique nearest one that passes the gap test (94 % of the steps of the bench image) -- and this
+// loop takes exactly that path in ~100 instructions: the six range words are read out back to back (one stall), the gap threshold is
+// computed while the LDS reads are in flight, validity / used flags are vector selects, every lane settles reading direction and next cursor
+// of its own candidate, the winner lane itself writes the used flag (exec = the one-bit tie mask), the result leaves through v_writelane.
+// Anything else (empty or crowded window, a tie, a failed gap test, the border rows) leaves the loop BEFORE the step has changed anything;
+// the caller then takes that one step with the compiled code.  Same arithmetic as the compiled step (unfused float ops, the same integer test).
+// Returns 0: step == n; 1: 64 results are in `ringv` (step is a multiple of 64); 2..7: the step at `step` is the caller's (the reason: see the exits).
+__device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigned& ringv, int n, int sh, int G, unsigned lds_p, unsigned lds_cst, unsigned lds_eid,
+                                            unsigned n_ent_m1, int rowoff, int isend, int lane, int& dbg_cnt) {
+    int ev; int s_cnt = 0;
+    int s_cx = __builtin_amdgcn_readfirstlane(cx), s_cy = __builtin_amdgcn_readfirstlane(cy), s_step = __builtin_amdgcn_readfirstlane(step);
+    const int s_n = __builtin_amdgcn_readfirstlane(n), s_sh = __builtin_amdgcn_readfirstlane(sh), s_G = __builtin_amdgcn_readfirstlane(G), s_Gm1 = s_G - 1;
+    const unsigned s_p = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_p), s_cst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_cst),
+                   s_eid = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_eid), s_nem1 = (unsigned)__builtin_amdgcn_readfirstlane((int)n_ent_m1);
+    // ordinal T inside the window -> byte address Q of its entry (clamped into the table): row 0 holds the ordinals [0, n0), row 1 [n0, n01), row 2 the rest
+#define ORIP_NN_Q(T, Q, TMP1, TMP2)                                                                                    \
+        "v_cmp_gt_u32_e64 s[94:95], s73, " T "\n\t"                 /* (a vector compare's SGPR result is read two instructions later at the earliest) */ \
+        "v_cmp_gt_u32 vcc, s68, " T "\n\t"                                                                             \
+        "v_add_u32 " Q ", s67, " T "\n\t"                                                                              \
+        "v_add_u32 " TMP1 ", s75, " T "\n\t"                                                                           \
+        "v_add_u32 " TMP2 ", s76, " T "\n\t"                                                                           \
+        "v_cndmask_b32_e64 " TMP1 ", " TMP2 ", " TMP1 ", s[94:95]\n\t"                                                 \
+        "v_cndmask_b32 " Q ", " TMP1 ", " Q ", vcc\n\t"                                                                \
+        "v_min_u32 " Q ", %[nem1], " Q "\n\t"                                                                          \
+        "v_lshl_add_u32 " Q ", " Q ", 1, %[eidb]\n\t"
+    // entry word IDW (index << 1 | end) -> its end bit, the address PA of the polyline's end points, and their read into v[E0:E1] issued
+#define ORIP_NN_FETCH(IDW, ENDBIT, PA, E0, E1)                                                                         \
+        "v_lshrrev_b32 v50, 1, " IDW "\n\t"                                                                            \
+        "v_lshl_add_u32 " PA ", v50, 3, %[pb]\n\t"                                                                     \
+        "ds_read_b64 v[" E0 ":" E1 "], " PA "\n\t"                                                                     \
+        "v_and_b32 " ENDBIT ", 1, " IDW "\n\t"
+    // key K of the candidate (squared distance pattern of the entry's end point; ~0 when the polyline is used or the ordinal lies beyond the window)
+#define ORIP_NN_KEY(ENDBIT, K, E0, E1, VALID)                                                                          \
+        "v_cmp_eq_u32_e64 s[94:95], 0, " ENDBIT "\n\t"                                                                 \
+        "v_and_b32 v54, 0x7fff7fff, v" E0 "\n\t"                                                                       \
+        "v_and_b32 v55, 0x8000, v" E0 "\n\t"                                                                           \
+        "v_cndmask_b32_e64 v50, v" E1 ", v54, s[94:95]\n\t"                                                            \
+        "v_cvt_f32_u32_sdwa v56, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\t"                          \
+        "v_cvt_f32_u32_sdwa v57, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"                          \
+        "v_sub_f32 v56, v56, v40\n\t"                                                                                  \
+        "v_sub_f32 v57, v57, v41\n\t"                                                                                  \
+        "v_mul_f32 v56, v56, v56\n\t"                                                                                  \
+        "v_mul_f32 v57, v57, v57\n\t"                                                                                  \
+        "v_add_f32 " K ", v56, v57\n\t"                                                                                \
+        "v_cmp_eq_u32 vcc, 0, v55\n\t"                                                                                 \
+        "v_cndmask_b32 " K ", -1, " K ", vcc\n\t"                                                                      \
+        "v_cndmask_b32_e64 " K ", -1, " K ", " VALID "\n\t"
+    // (entry word, K) in v[IK0:IK1], end points v[E0:E1], address PA: better than the best so far (v[58:59], v[52:53], v51)?  Smaller key, then smaller entry word.
+#define ORIP_NN_MERGE(IK0, IK1, E0, E1, PA)                                                                            \
+        "v_cmp_lt_u64 vcc, v[" IK0 ":" IK1 "], v[58:59]\n\t"                                                           \
+        "v_cndmask_b32 v58, v58, v" IK0 ", vcc\n\t"                                                                    \
+        "v_cndmask_b32 v59, v59, v" IK1 ", vcc\n\t"                                                                    \
+        "v_cndmask_b32 v52, v52, v" E0 ", vcc\n\t"                                                                     \
+        "v_cndmask_b32 v53, v53, v" E1 ", vcc\n\t"                                                                     \
+        "v_cndmask_b32 v51, v51, " PA ", vcc\n\t"
+    // minimum of v47 over the wave into lane 63 (the compiler's sequence for the same reduction; a DPP source is read two instructions after it was written)
+#define ORIP_NN_MIN6                                                                                                   \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                         \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                         \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                         \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                         \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                      \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_min_u32_dpp v47, v47, v47 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                      \
+        "s_nop 1\n\t"
+    asm volatile(
+        "s_mov_b32 s89, m0\n\t"
+        "s_and_b32 m0, %[step], 63\n\t"
+        "s_lshl_b32 s87, 1, %[sh]\n\t"                              // cell
+        "s_add_i32 s88, s87, -1\n\t"                                // cell - 1
+        "s_add_i32 s79, s87, 1\n\t"
+        "s_mul_i32 s100, s79, s79\n\t"
+        "s_lshr_b32 s80, s100, 18\n\t"
+        "s_sub_i32 s100, s100, s80\n\t"
+        "s_add_i32 s100, s100, -1\n\t"                              // the gap test's threshold for the smallest gap a 3x3 window can have (cell + 1)
+        "s_mov_b32 s81, -1\n\t"                                     // cell the range words in s67 .. s76 belong to: none yet
+        "s_mov_b32 s99, 0\n\t"                                      // 1: the lanes hold the candidates of that cell's window (v45, v49, v51, v[52:53], s[92:93])
+        "v_cvt_f32_i32 v40, %[cx]\n\t"
+        "v_cvt_f32_i32 v41, %[cy]\n\t"
+        "L_step%=:\n\t"
+        "s_lshr_b32 s60, %[cx], %[sh]\n\t"
+        "s_lshr_b32 s61, %[cy], %[sh]\n\t"
+        "s_lshl_b32 s79, s61, 16\n\t"
+        "s_or_b32 s79, s79, s60\n\t"
+        "s_cmp_eq_u32 s79, s81\n\t"
+        "s_cbranch_scc1 L_samecell%=\n\t"
+        // ---- another cell: the window's range words
+        "s_mov_b32 s81, s79\n\t"
+        "s_mov_b32 s99, 0\n\t"
+        "s_sub_i32 s62, s60, 1\n\t"
+        "s_max_i32 s62, s62, 0\n\t"                                 // x0
+        "s_add_i32 s63, s60, 1\n\t"
+        "s_min_i32 s63, s63, %[Gm1]\n\t"
+        "s_add_i32 s63, s63, 1\n\t"                                 // x1 + 1
+        "s_sub_i32 s64, s61, 1\n\t"
+        "s_max_i32 s64, s64, 0\n\t"                                 // y0
+        "s_add_i32 s65, s61, 1\n\t"
+        "s_min_i32 s65, s65, %[Gm1]\n\t"
+        "s_sub_i32 s65, s65, s64\n\t"                               // y1 - y0: 2, or 1 in the first / last cell row
+        "s_sub_i32 s66, s63, s62\n\t"
+        "v_add_u32 v42, s64, %[rowoff]\n\t"                         // lanes 0..5: row of the range word, ...
+        "v_mul_u32_u24 v43, s66, %[isend]\n\t"
+        "v_add_u32 v43, s62, v43\n\t"                               // ... its cell column (x0: start of the row's range, x1 + 1: its end)
+        "v_mad_u32_u24 v42, v42, %[G], v43\n\t"
+        "v_lshl_add_u32 v42, v42, 2, %[cstb]\n\t"
+        "ds_read_b32 v44, v42\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readlane_b32 s67, v44, 0\n\t"
+        "v_readlane_b32 s68, v44, 1\n\t"
+        "v_readlane_b32 s69, v44, 2\n\t"
+        "v_readlane_b32 s70, v44, 3\n\t"
+        "v_readlane_b32 s71, v44, 4\n\t"
+        "v_readlane_b32 s72, v44, 5\n\t"
+        "s_sub_i32 s68, s68, s67\n\t"                               // n0
+        "s_sub_i32 s70, s70, s69\n\t"                               // n1
+        "s_sub_i32 s72, s72, s71\n\t"                               // n2 ...
+        "s_cmp_lt_u32 s65, 2\n\t"
+        "s_cselect_b32 s72, 0, s72\n\t"                             // ... none when the third row lies outside the grid
+        "s_add_i32 s73, s68, s70\n\t"                               // n01
+        "s_add_i32 s74, s73, s72\n\t"                               // total
+        "s_sub_i32 s75, s69, s68\n\t"                               // lo1 - n0
+        "s_sub_i32 s76, s71, s73\n\t"                               // lo2 - n01
+        "s_nop 1\n\t"
+        "s_branch L_ranges%=\n\t"
+        "L_samecell%=:\n\t"                                          // the lanes may still hold this window's candidates: then no LDS read at all
+        "s_cmp_eq_u32 s99, 1\n\t"
+        "s_cbranch_scc1 L_hit1%=\n\t"
+        "s_cmp_eq_u32 s99, 2\n\t"
+        "s_cbranch_scc1 L_hit2%=\n\t"
+        "L_ranges%=:\n\t"
+        "s_cmp_eq_u32 s74, 0\n\t"
+        "s_cbranch_scc1 L_fb3%=\n\t"
+        "s_cmp_gt_u32 s74, 64\n\t"
+        "s_cbranch_scc1 L_many%=\n\t"
+        // ---- up to 64 candidates: one per lane, kept in the lanes while the cursor stays in the cell
+        ORIP_NN_Q("%[lane]", "v46", "v47", "v48")
+        "ds_read_u16 v49, v46\n\t"
+        "v_cmp_gt_u32_e64 s[92:93], s74, %[lane]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        ORIP_NN_FETCH("v49", "v45", "v51", "52", "53")
+        "s_mov_b32 s99, 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "L_key%=:\n\t"
+        ORIP_NN_KEY("v45", "v59", "52", "53", "s[92:93]")
+        "v_mov_b32 v58, v49\n\t"
+        "s_branch L_best%=\n\t"
+        // ---- 65 .. 128 candidates: two per lane (A: v66, v70, v65, v[68:69], s[92:93]; B: v76, v71, v73, v[74:75], s[96:97]), kept like the single ones
+        "L_many%=:\n\t"
+        "s_cmp_gt_u32 s74, 128\n\t"
+        "s_cbranch_scc1 L_loop%=\n\t"
+        "v_add_u32 v43, 64, %[lane]\n\t"
+        ORIP_NN_Q("%[lane]", "v46", "v47", "v48")
+        "ds_read_u16 v66, v46\n\t"
+        ORIP_NN_Q("v43", "v72", "v47", "v48")
+        "ds_read_u16 v76, v72\n\t"
+        "v_cmp_gt_u32_e64 s[92:93], s74, %[lane]\n\t"
+        "v_cmp_gt_u32_e64 s[96:97], s74, v43\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        ORIP_NN_FETCH("v66", "v70", "v65", "68", "69")
+        ORIP_NN_FETCH("v76", "v71", "v73", "74", "75")
+        "s_mov_b32 s99, 2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "L_key2%=:\n\t"
+        ORIP_NN_KEY("v70", "v67", "68", "69", "s[92:93]")
+        ORIP_NN_KEY("v71", "v77", "74", "75", "s[96:97]")
+        "v_mov_b32 v58, v66\n\t"
+        "v_mov_b32 v59, v67\n\t"
+        "v_mov_b32 v52, v68\n\t"
+        "v_mov_b32 v53, v69\n\t"
+        "v_mov_b32 v51, v65\n\t"
+        ORIP_NN_MERGE("76", "77", "74", "75", "v73")
+        "s_branch L_best%=\n\t"
+        // ---- more than 128: 128 per turn, the two halves' LDS reads in flight together; nothing is kept
+        "L_loop%=:\n\t"
+        "s_add_i32 %[cnt], %[cnt], 0x100000\n\t"
+        "s_mov_b32 s99, 0\n\t"
+        "s_mov_b32 s98, 0\n\t"
+        "v_mov_b32 v58, -1\n\t"
+        "v_mov_b32 v59, -1\n\t"
+        "v_mov_b32 v52, 0\n\t"
+        "v_mov_b32 v53, 0\n\t"
+        "v_mov_b32 v51, 0\n\t"
+        "L_pair%=:\n\t"
+        "v_add_u32 v42, s98, %[lane]\n\t"
+        "v_add_u32 v43, 64, v42\n\t"
+        ORIP_NN_Q("v42", "v46", "v47", "v48")
+        "ds_read_u16 v66, v46\n\t"
+        ORIP_NN_Q("v43", "v72", "v47", "v48")
+        "ds_read_u16 v76, v72\n\t"
+        "v_cmp_gt_u32_e64 s[92:93], s74, v42\n\t"
+        "v_cmp_gt_u32_e64 s[96:97], s74, v43\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        ORIP_NN_FETCH("v66", "v70", "v65", "68", "69")
+        ORIP_NN_FETCH("v76", "v71", "v73", "74", "75")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        ORIP_NN_KEY("v70", "v67", "68", "69", "s[92:93]")
+        ORIP_NN_KEY("v71", "v77", "74", "75", "s[96:97]")
+        ORIP_NN_MERGE("66", "67", "68", "69", "v65")
+        ORIP_NN_MERGE("76", "77", "74", "75", "v73")
+        "s_add_i32 s98, s98, 128\n\t"
+        "s_cmp_lt_u32 s98, s74\n\t"
+        "s_cbranch_scc1 L_pair%=\n\t"
+        "L_best%=:\n\t"
+        // ---- every lane: the next cursor if its candidate wins; the wave: the smallest key.  The winner is read backwards exactly when its
+        // END entry won: had the start been as near or nearer it would hold a key as small or smaller (the gap test says every entry nearer
+        // than the gap was scanned), and on equal keys the smaller entry word -- the start -- is taken below.  So entry word == index << 1 | flip.
+        "v_mov_b32 v47, v59\n\t"
+        "v_and_b32 v54, 0x7fff7fff, v52\n\t"
+        "v_and_b32 v64, 1, v58\n\t"
+        "v_min_u32_dpp v47, v47, v47 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"
+        "v_cmp_gt_i32_e64 s[90:91], 0, v52\n\t"                     // closed (bit 31)
+        "v_min_u32_dpp v47, v47, v47 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 v62, v53, v54, vcc\n\t"
+        "v_or_b32 v60, 0x8000, v52\n\t"
+        "v_min_u32_dpp v47, v47, v47 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 v62, v62, v54, s[90:91]\n\t"             // next cursor: the start when closed or read backwards, else the end
+        "s_nop 0\n\t"
+        "v_min_u32_dpp v47, v47, v47 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v47, v47, v47 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp v47, v47, v47 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 s77, v47, 63\n\t"
+        "s_cmp_eq_u32 s77, -1\n\t"
+        "s_cbranch_scc1 L_fb5%=\n\t"
+        "v_cvt_u32_f32 v48, s77\n\t"
+        "v_add_u32 v48, 1, v48\n\t"
+        "v_cmp_ge_u32 vcc, s100, v48\n\t"
+        "s_and_b64 s[94:95], vcc, exec\n\t"
+        "s_cbranch_scc0 L_gap%=\n\t"
+        "L_gapok%=:\n\t"
+        "v_cmp_eq_u32_e64 s[82:83], s77, v59\n\t"
+        "s_bcnt1_i32_b64 s79, s[82:83]\n\t"
+        "s_cmp_eq_u32 s79, 1\n\t"
+        "s_cbranch_scc1 L_win%=\n\t"
+        // several lanes at the smallest distance: the smallest entry word among them (07:67 -- the first polyline in list order, its start first)
+        "v_cndmask_b32_e64 v47, -1, v58, s[82:83]\n\t"
+        ORIP_NN_MIN6
+        "v_readlane_b32 s79, v47, 63\n\t"
+        "s_nop 1\n\t"
+        "v_cmp_eq_u32_e64 s[94:95], s79, v58\n\t"
+        "s_and_b64 s[82:83], s[82:83], s[94:95]\n\t"
+        "L_win%=:\n\t"
+        "s_ff1_i32_b64 s84, s[82:83]\n\t"
+        "v_readlane_b32 s85, v58, s84\n\t"
+        "v_readlane_b32 s86, v62, s84\n\t"
+        "s_mov_b64 s[90:91], exec\n\t"
+        "s_mov_b64 exec, s[82:83]\n\t"
+        "ds_write_b32 v51, v60\n\t"                                 // the used flag, by the winning lane
+        "s_mov_b64 exec, s[90:91]\n\t"
+        "v_writelane_b32 %[ringv], s85, m0\n\t"
+        // the lanes' copies of the winner's end points (its other entry may sit in this window too) take the flag as well
+        "s_lshr_b32 s79, s85, 1\n\t"
+        "s_cmp_eq_u32 s99, 2\n\t"
+        "s_cbranch_scc1 L_upd2%=\n\t"
+        "v_lshrrev_b32 v50, 1, v49\n\t"
+        "v_or_b32 v55, 0x8000, v52\n\t"
+        "v_cmp_eq_u32 vcc, s79, v50\n\t"
+        "v_cndmask_b32 v52, v52, v55, vcc\n\t"
+        "s_branch L_next%=\n\t"
+        "L_upd2%=:\n\t"
+        "v_lshrrev_b32 v50, 1, v66\n\t"
+        "v_or_b32 v55, 0x8000, v68\n\t"
+        "v_cmp_eq_u32 vcc, s79, v50\n\t"
+        "v_cndmask_b32 v68, v68, v55, vcc\n\t"
+        "v_lshrrev_b32 v50, 1, v76\n\t"
+        "v_or_b32 v55, 0x8000, v74\n\t"
+        "v_cmp_eq_u32 vcc, s79, v50\n\t"
+        "v_cndmask_b32 v74, v74, v55, vcc\n\t"
+        "L_next%=:\n\t"
+        "s_and_b32 %[cx], s86, 0xffff\n\t"
+        "s_lshr_b32 %[cy], s86, 16\n\t"
+        "v_cvt_f32_i32 v40, %[cx]\n\t"
+        "v_cvt_f32_i32 v41, %[cy]\n\t"
+        "s_add_i32 %[step], %[step], 1\n\t"
+        "s_add_i32 m0, m0, 1\n\t"
+        "s_cmp_eq_u32 m0, 64\n\t"
+        "s_cbranch_scc1 L_flush%=\n\t"
+        "s_cmp_ge_u32 %[step], %[n]\n\t"
+        "s_cbranch_scc1 L_done%=\n\t"
+        "s_branch L_step%=\n\t"
+        // ---- the nearest candidate is farther than cell + 1: the exact gap = cell + min over x and y of min(l + 1, cell - l), l = cursor inside its cell
+        "L_gap%=:\n\t"
+        "s_and_b32 s79, %[cx], s88\n\t"
+        "s_sub_i32 s80, s87, s79\n\t"
+        "s_add_i32 s79, s79, 1\n\t"
+        "s_min_i32 s79, s79, s80\n\t"
+        "s_and_b32 s80, %[cy], s88\n\t"
+        "s_sub_i32 s78, s87, s80\n\t"
+        "s_add_i32 s80, s80, 1\n\t"
+        "s_min_i32 s80, s80, s78\n\t"
+        "s_min_i32 s79, s79, s80\n\t"
+        "s_add_i32 s79, s79, s87\n\t"
+        "s_mul_i32 s78, s79, s79\n\t"
+        "s_lshr_b32 s80, s78, 18\n\t"
+        "s_sub_i32 s78, s78, s80\n\t"
+        "s_add_i32 s78, s78, -1\n\t"
+        "v_cmp_ge_u32 vcc, s78, v48\n\t"
+        "s_and_b64 s[94:95], vcc, exec\n\t"
+        "s_cbranch_scc1 L_gapok%=\n\t"
+        "s_mov_b32 %[ev], 6\n\t"                                       // 6: the gap test wants a wider window
+        "s_branch L_out%=\n\t"
+        "L_hit1%=:\n\t"
+        "s_add_i32 %[cnt], %[cnt], 1\n\t"
+        "s_branch L_key%=\n\t"
+        "L_hit2%=:\n\t"
+        "s_add_i32 %[cnt], %[cnt], 0x400\n\t"
+        "s_branch L_key2%=\n\t"
+        "L_fb3%=:\n\t"                                                 // 3: empty window
+        "s_mov_b32 %[ev], 3\n\t"
+        "s_branch L_out%=\n\t"
+        "L_fb5%=:\n\t"                                                 // 5: every candidate used
+        "s_mov_b32 %[ev], 5\n\t"
+        "s_branch L_out%=\n\t"
+        "L_flush%=:\n\t"
+        "s_mov_b32 %[ev], 1\n\t"
+        "s_branch L_out%=\n\t"
+        "L_done%=:\n\t"
+        "s_mov_b32 %[ev], 0\n\t"
+        "L_out%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 m0, s89\n\t"
+        : [ev] "=&s"(ev), [cx] "+s"(s_cx), [cy] "+s"(s_cy), [step] "+s"(s_step), [ringv] "+v"(ringv), [cnt] "+s"(s_cnt)
+        : [n] "s"(s_n), [sh] "s"(s_sh), [G] "s"(s_G), [Gm1] "s"(s_Gm1), [cstb] "s"(s_cst), [eidb] "s"(s_eid), [pb] "s"(s_p), [nem1] "s"(s_nem1),
+          [rowoff] "v"(rowoff), [isend] "v"(isend), [lane] "v"(lane)
+        : "vcc", "scc", "memory",
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
+          "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
+          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77");
+#undef ORIP_NN_Q
+#undef ORIP_NN_FETCH
+#undef ORIP_NN_KEY
+#undef ORIP_NN_MERGE
+#undef ORIP_NN_MIN6
+    cx = s_cx; cy = s_cy; step = s_step; dbg_cnt = s_cnt;
+    return ev;
+}
+
 // The same search with a step written for the way a lone wave executes (one instruction per ~4.5 cycles, +16..20 cycles whenever the scalar
 // unit consumes a value produced by a vector instruction, every exec-mask juggle of divergent control flow a handful of both):
 // k_greedy_nn_grid's step compiles to ~350 instructions with divergent loops around uniform values = 1.1 us per step.  Here
@@ -731,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restri
 //     squared distance stay below 2^-22 relative): conservative, so at worst one more round is scanned, never a wrong winner;
 //   * results leave through a VGPR (one lane per step, 64 at a time).
 __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07, int G,
-                                                        int32_t* __restrict__ order, uint8_t* __restrict__ flips) {
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ flips, int no_asm, unsigned long long* __restrict__ dbg) {
     ORIP_NN_GATE(sel, skip_if, need_any)
     extern __shared__ __align__(16) unsigned char smem[];
     uint2* P = reinterpret_cast<uint2*>(smem);                                     // .x = sx | sy << 16, .y = ex | ey << 16; bit 15 of sx: used, bit 15 of sy: closed (rule07)
@@ -783,11 +1132,28 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
     { const uint2 e = P[seed]; const bool cl = (e.x & 0x80000000u) != 0; cx = NNU(cl ? (e.x & 0x7fff) : (e.y & 0xffff)); cy = NNU(cl ? ((e.x >> 16) & 0x7fff) : (e.y >> 16)); }
     unsigned ringv = lane == 0 ? (unsigned)(seed << 1) : 0u;                      // lane (step & 63): index << 1 | flip of that step
     const int Gm1 = G - 1;
-    for (int step = 1; step < n; step++) {
+    const bool use_asm = G >= 4 && !no_asm;
+    const unsigned lds_p = (unsigned)(uintptr_t)P, lds_cst = (unsigned)(uintptr_t)cst, lds_eid = (unsigned)(uintptr_t)Eid;
+    const int rowoff = lane < 6 ? (lane >> 1) : 0, isend = lane < 6 ? (lane & 1) : 0;
+    int step = 1, r_first = 1;
+    unsigned long long d_fb = 0, d_calls = 0, t_asm = 0, t_gen = 0;      // ORIP_NN_DBG2: steps taken by the compiled code, asm entries, cycles in either
+    while (step < n) {
+        if (use_asm) {
+            const unsigned long long t_0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+            int cnt = 0;
+            const int ev = nn_asm_steps(cx, cy, step, ringv, n, sh, G, lds_p, lds_cst, lds_eid, n_ent - 1u, rowoff, isend, lane, cnt);
+            if (dbg) { t_asm += __builtin_amdgcn_s_memtime() - t_0; d_calls++; if (lane == 0) { if (ev >= 2) dbg[2 + ev]++; dbg[4] += (unsigned)cnt & 0x3ffu; dbg[6] += ((unsigned)cnt >> 10) & 0x3ffu; dbg[9] += (unsigned)cnt >> 20; } }
+            if (ev == 1) { order[step - 64 + lane] = (int32_t)(ringv >> 1); flips[step - 64 + lane] = (uint8_t)(ringv & 1u); continue; }
+            if (ev == 0) break;
+            r_first = 3;                          // the 3x3 window has just been found wanting (empty, all used, or the nearest lies beyond the gap): the next one
+        }
+        // ---- one step with the compiled code: whatever the loop above does not take
+        const unsigned long long t_g0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+        d_fb++;
         const int gx = cx >> sh, gy = cy >> sh;
         const float fx = (float)cx, fy = (float)cy;
         unsigned wi = 0, w0 = 0, w1 = 0;
-        for (int r = 1;; r = 2 * r + 1) {
+        for (int r = r_first;; r = 2 * r + 1) {
             const int x0 = max(0, gx - r), x1 = min(Gm1, gx + r), y0 = max(0, gy - r), y1 = min(Gm1, gy + r);
             unsigned myk = ~0u, myi = 0x7fffffffu, my0 = 0, my1 = 0;
             // entry `q` (clamped into the table) as a candidate; valid == false: counts as infinitely far
@@ -875,7 +1241,10 @@ __global__ __launch_bounds__(64) void k_greedy_nn_fast(const NNEnds* __restrict_
         ringv = lane == (step & 63) ? wi : ringv;
         if ((step & 63) == 63) { order[step - 63 + lane] = (int32_t)(ringv >> 1); flips[step - 63 + lane] = (uint8_t)(ringv & 1u); }
         cx = (int)(w1 & 0xffffu); cy = (int)(w1 >> 16);
+        step++;
+        if (dbg) t_gen += __builtin_amdgcn_s_memtime() - t_g0;
     }
+    if (dbg && lane == 0) { dbg[0] = d_fb; dbg[1] = d_calls; dbg[2] = t_asm; dbg[3] = t_gen; }
     { const int done = n & ~63; if (done + lane < n) { order[done + lane] = (int32_t)(ringv >> 1); flips[done + lane] = (uint8_t)(ringv & 1u); } }
 #undef NNU
 }
@@ -926,7 +1295,12 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
         unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
         if (grid_ok) {
             if (dbg || getenv("ORIP_NN_OLDGRID")) hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, dbg);
-            else hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips);
+            else {
+                unsigned long long* dbg2 = getenv("ORIP_NN_DBG2") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
+                if (dbg2) hipMemsetAsync(dbg2, 0, 80, LN(c).stream);
+                hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, getenv("ORIP_NN_NOASM") ? 1 : 0, dbg2);
+                if (dbg2) { unsigned long long h[10]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg2, 80, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg2] kind %d n %lld G %d: %llu steps by the compiled code (empty %llu, all used %llu, gap %llu; asm steps from cached candidates: one per lane %llu, two per lane %llu; with more than 128 candidates %llu), %llu asm entries, cycles asm %llu compiled %llu\n", kind, (long long)n, G, h[0], h[5], h[7], h[8], h[4], h[6], h[9], h[1], h[2], h[3]); hipMemsetAsync(dbg2, 0, 80, LN(c).stream); }
+            }
             if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
         }
         if (lds_ok) hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, d_seed, 1, grid_ok ? 2 : 0, r07, order, flips);   // with a grid candidate: only when the grid bowed out
