@@ -9,9 +9,32 @@
 namespace {   // every TU that includes this header gets its own copy of the kernels (internal linkage)
 
 // ---- rocPRIM wrappers (temporary storage in ctx->tmpF) ----
+// exclusive prefix sums of up to 32 768 integers by ONE workgroup (thread t owns the items [t * per, (t + 1) * per)): the lists of this path are a few
+// thousand polylines long, and rocPRIM's scan is two dispatches (look-back state, scan) at ~50 us each on a queue that shares the card.  in == out is fine.
+template <class T>
+__global__ __launch_bounds__(1024) void k_scan_small(const T* in, T* out, unsigned n, unsigned per) {
+    __shared__ T wsum[16];
+    const unsigned tid = threadIdx.x, lo = tid * per, hi = min(n, lo + per);
+    T mine = 0;
+    for (unsigned i = lo; i < hi; i++) mine += in[i];
+    T inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(inc, o, 64); if ((int)(tid & 63u) >= o) inc += t; }
+    if ((tid & 63u) == 63u) wsum[tid >> 6] = inc;
+    __syncthreads();
+    T base = 0;
+    for (unsigned w = 0; w < (tid >> 6); w++) base += wsum[w];
+    T run = base + inc - mine;
+    __syncthreads();
+    for (unsigned i = lo; i < hi; i++) { const T v = in[i]; out[i] = run; run += v; }
+}
 template <class T>
 static int vscan_excl(orip_ctx* c, const T* in, T* out, size_t n) {
     if (n == 0) return 0;
+    if (n <= 32768) {
+        hipLaunchKernelGGL(k_scan_small<T>, dim3(1), dim3(1024), 0, LN(c).stream, in, out, (unsigned)n, (unsigned)cdiv((int64_t)n, 1024));
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     size_t bytes = 0;
     HIPC(c, rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), LN(c).stream));
     HIPC(c, LN(c).tmpF.ensure(bytes + 16));
