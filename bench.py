@@ -79,8 +79,8 @@ PMC_NAMES = {"k_trace": ["k_trace"], "k_write_walks": ["k_vown"], "k_lab_assign"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096, help="image side (BASELINE: 4096)")
     ap.add_argument("--layers", type=int, default=8, help="colour layers (BASELINE: 8)")
     ap.add_argument("--upto", type=int, default=12, choices=[3, 12], help="3: stages 02 + 03 only (BASELINE config C2, use with --size 2048)")
