@@ -576,20 +576,42 @@ __global__ __launch_bounds__(256) void k_caps_init(CapSlot* __restrict__ tab, un
 }
 __global__ __launch_bounds__(256) void k_caps_insert(SampleArrs A, const unsigned* __restrict__ sbase, const int* __restrict__ capprev, unsigned MS,
                                                       CapSlot* tab, unsigned long long tmask, int max_probe, int* __restrict__ overflow) {
-    unsigned g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= MS) return;
-    unsigned b = sbase[A.rank[g]];
-    int cp = capprev ? capprev[g] : (g > b ? (int)(g - b) - 1 : -1);      // capprev == nullptr: every sample is on the canvas, so the capsule runs from the previous sample
-    if (cp < 0) return;
-    unsigned long long key = cap_key(A.xi[b + cp], A.yi[b + cp], A.xi[g], A.yi[g]);
-    unsigned long long h = hash64(key) & tmask;
-    for (int probe = 0;; probe++) {
-        if (probe >= max_probe) { *overflow = 1; return; }      // table too small for the number of distinct capsules: the host retries larger
-        const uint4 s = *reinterpret_cast<const uint4*>(&tab[h]);      // key and value in one 16-byte load (every probe reads another slot)
-        unsigned long long cur = ((unsigned long long)s.y << 32) | s.x;
-        if (cur == 0) { unsigned long long old = atomicCAS(&tab[h].key, 0ULL, key); if (old == 0 || old == key) cur = key; else cur = old; }
-        if (cur == key) { if (s.z > g) atomicMin(&tab[h].val, g); return; }    // the minimum only decreases: a stale read can only cost a useless atomic
-        h = (h + 1) & tmask;
+    // Four samples per thread, a block's 1024 samples apart by 256: the chain rank -> base -> pixels -> slot is four dependent loads deep, and with one
+    // sample per thread the kernel waits for them one after the other (1 TB/s of the card's 8 with every wave slot full); four independent chains per
+    // thread keep four times as many loads in flight.
+    constexpr int S = 4;
+    const unsigned g0 = blockIdx.x * (256 * S) + threadIdx.x;
+    unsigned g[S], bb[S]; int cp[S]; bool on[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) { g[u] = g0 + 256u * u; on[u] = g[u] < MS; bb[u] = on[u] ? A.rank[g[u]] : 0u; }
+#pragma unroll
+    for (int u = 0; u < S; u++) if (on[u]) bb[u] = sbase[bb[u]];
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        cp[u] = !on[u] ? -1 : (capprev ? capprev[g[u]] : (g[u] > bb[u] ? (int)(g[u] - bb[u]) - 1 : -1));      // capprev == nullptr: every sample is on the canvas, so the capsule runs from the previous sample
+        on[u] = cp[u] >= 0;
+    }
+    unsigned long long key[S], h[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        key[u] = 0; h[u] = 0;
+        if (on[u]) { key[u] = cap_key(A.xi[bb[u] + cp[u]], A.yi[bb[u] + cp[u]], A.xi[g[u]], A.yi[g[u]]); h[u] = hash64(key[u]) & tmask; }
+    }
+    uint4 sl[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) sl[u] = on[u] ? *reinterpret_cast<const uint4*>(&tab[h[u]]) : make_uint4(0, 0, 0, 0);      // first probes of all four in flight together
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        if (!on[u]) continue;
+        uint4 s = sl[u]; unsigned long long hh = h[u];
+        for (int probe = 0;; probe++) {
+            if (probe >= max_probe) { *overflow = 1; break; }      // table too small for the number of distinct capsules: the host retries larger
+            if (probe) s = *reinterpret_cast<const uint4*>(&tab[hh]);      // key and value in one 16-byte load (every probe reads another slot)
+            unsigned long long cur = ((unsigned long long)s.y << 32) | s.x;
+            if (cur == 0) { unsigned long long old = atomicCAS(&tab[hh].key, 0ULL, key[u]); if (old == 0 || old == key[u]) cur = key[u]; else cur = old; }
+            if (cur == key[u]) { if (s.z > g[u]) atomicMin(&tab[hh].val, g[u]); break; }    // the minimum only decreases: a stale read can only cost a useless atomic
+            hh = (hh + 1) & tmask;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_caps_stamp(const CapSlot* __restrict__ tab, unsigned long long tsize,
@@ -1576,7 +1598,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 hipLaunchKernelGGL(k_caps_init, dim3((unsigned)cdiv(tsize, 256)), dim3(256), 0, LN(c).stream, tab, tsize);
                 HIPC(c, hipMemsetAsync(d_ovf, 0, 4, LN(c).stream));
                 const int max_probe = tsize >= tfull ? 0x7fffffff : 96;
-                { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tab, tsize - 1, max_probe, d_ovf); }
+                { ProfScope ps(c, "k_caps_insert"); hipLaunchKernelGGL(k_caps_insert, dim3(cdiv(MS, 1024)), dim3(256), 0, LN(c).stream, A, sbase, capprev, MS, tab, tsize - 1, max_probe, d_ovf); }
                 int ovf = 0; ORIP_TRY(vread(c, &ovf, d_ovf));
                 if (!ovf) break;
             }
