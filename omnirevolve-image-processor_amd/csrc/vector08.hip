@@ -295,49 +295,101 @@ template <class Src>
 __global__ __launch_bounds__(256) void k_samples(Src src, const int64_t* __restrict__ cumoff, const float* __restrict__ cum,
                                                   const RsInfo* __restrict__ info, const unsigned* __restrict__ ord, const unsigned* __restrict__ sbase, int64_t n_rank,
                                                   unsigned MS, double step, int W, int H, SampleArrs A, double inv_cell, unsigned* __restrict__ ckeys, unsigned* __restrict__ cvals,
-                                                  const int2* __restrict__ hints, unsigned long long* __restrict__ pixbits, int Wq, unsigned* __restrict__ firstseq) {
-    __shared__ double shx[256], shy[256];
-    const unsigned g = blockIdx.x * 256 + threadIdx.x;
-    const bool act = g < MS;
-    double x = 0.0, y = 0.0; unsigned j = 0;
+                                                  const int2* __restrict__ hints, unsigned nhb, unsigned long long* __restrict__ pixbits, int Wq, unsigned* __restrict__ firstseq) {
+    // FOUR consecutive samples per thread.  A sample costs a chain of ~18 dependent loads (rank, polyline, a bisection of its cumulative lengths, the
+    // segment's end points), and with one sample per thread the kernel sat at 1.5 TB/s with every wave slot taken.  Consecutive samples of a polyline
+    // lie a few segments apart (8 px of arc length against segments of 2 .. 3 px), so the second to fourth find their segment with ONE round of eight
+    // independent loads from where the previous one stood, and their predecessor (the tail bookkeeping's distance, 08:141,147) is in registers.
+    constexpr int S = 4;
+    __shared__ double shx[256], shy[256];                  // the thread's last sample: the predecessor of the next thread's first one
+    const unsigned g0 = (blockIdx.x * 256 + threadIdx.x) * S;
+    const bool act = g0 < MS;
+    double x0 = 0.0, y0 = 0.0, xl = 0.0, yl = 0.0; unsigned j0 = 0;
     if (act) {
-    const int2 h0 = hints[blockIdx.x];
-    const bool last = blockIdx.x + 1 == gridDim.x;
-    const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[blockIdx.x + 1];
-    int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g);      // sbase[h0.x] <= g already
-    unsigned i = ord[r]; j = g - sbase[r];
-    auto cu = src.cur(i); const float* s = cum + cumoff[i];
-    RsInfo ri = info[i];
-    // position of sample jj of this polyline, its segment known to lie in [klo, khi]
-    auto pos = [&](unsigned jj, int64_t klo, int64_t khi, double& px, double& py) {
-        if (ri.pass) { const int2 q = cu.at(jj); px = (double)(float)q.x; py = (double)(float)q.y; return; }
-        double t = (double)sample_t(jj, step);
-        int64_t k = sample_seg(s, ri.n_eff, t, klo, khi);
-        double sk = (double)s[k], sk1 = (double)s[k + 1];
-        double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
-        double a = __dsub_rn(1.0, u);
-        const int2 p0 = cu.at(k), p1 = cu.at(k + 1);
-        px = __dadd_rn(__dmul_rn((double)(float)p0.x, a), __dmul_rn((double)(float)p1.x, u));
-        py = __dadd_rn(__dmul_rn((double)(float)p0.y, a), __dmul_rn((double)(float)p1.y, u));
-    };
-    pos(j, (r == h0.x) ? h0.y : -1, (!last && r == h1.x) ? h1.y : ri.n_eff - 2, x, y);
-    long long xi = vs::round_half_even(x), yi = vs::round_half_even(y);
-    A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
-    bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
-    A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
-    if (pixbits && in) {       // the canvas is read at sample pixels only (k_caps_stamp_bits): mark the pixel, give it its "never stamped" value
-        unsigned long long* wp = &pixbits[(size_t)yi * Wq + (xi >> 6)]; const unsigned long long bit = 1ULL << (xi & 63);
-        if (!(*wp & bit) && !(atomicOr(wp, bit) & bit)) firstseq[(size_t)yi * W + xi] = 0xffffffffu;      // whoever sets the bit initialises the pixel: one write per distinct pixel, not per sample
+        const unsigned hb = g0 >> 8;                       // hints: rank and segment of every 256th sample (k_sample_hints)
+        const int2 h0 = hints[hb];
+        const bool last = hb + 1 == nhb;
+        const int2 h1 = last ? make_int2((int)n_rank - 1, 0) : hints[hb + 1];
+        int64_t r = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g0);      // sbase[h0.x] <= g0 already
+        unsigned i = ord[r]; unsigned j = g0 - sbase[r];
+        auto cu = src.cur(i); const float* s = cum + cumoff[i];
+        RsInfo ri = info[i];
+        int64_t kprev = -2;                                // segment of the previous sample of this polyline taken by this thread (-2: none)
+        double px = 0.0, py = 0.0;
+        j0 = j;
+        // position of sample jj of the current polyline, its segment known to lie in [klo, khi]
+        auto pos_at = [&](int64_t k, double t, double& ox, double& oy) {
+            double sk = (double)s[k], sk1 = (double)s[k + 1];
+            double u = __ddiv_rn(__dsub_rn(t, sk), fmax(1e-6, __dsub_rn(sk1, sk)));
+            double a = __dsub_rn(1.0, u);
+            const int2 p0 = cu.at(k), p1 = cu.at(k + 1);
+            ox = __dadd_rn(__dmul_rn((double)(float)p0.x, a), __dmul_rn((double)(float)p1.x, u));
+            oy = __dadd_rn(__dmul_rn((double)(float)p0.y, a), __dmul_rn((double)(float)p1.y, u));
+        };
+#pragma unroll 1
+        for (int u = 0; u < S; u++) {
+            const unsigned g = g0 + (unsigned)u;
+            if (g >= MS) break;
+            if (u > 0 && j >= ri.m) {                      // the polyline is used up: on to the next one that has samples
+                do { r++; i = ord[r]; ri = info[i]; } while (ri.m == 0);
+                j = 0; cu = src.cur(i); s = cum + cumoff[i]; kprev = -2;
+            }
+            double x, y;
+            if (ri.pass) { const int2 q = cu.at(j); x = (double)(float)q.x; y = (double)(float)q.y; }
+            else {
+                const double t = (double)sample_t(j, step);
+                int64_t k;
+                if (kprev < -1) {
+                    const bool first = u == 0;
+                    k = sample_seg(s, ri.n_eff, t, (first && r == h0.x) ? h0.y : -1, (first && !last && r == h1.x) ? h1.y : ri.n_eff - 2);
+                } else {
+                    // searchsorted(s, t, 'right') - 1, clipped, from the previous sample's segment on: eight lengths per round
+                    k = kprev < 0 ? 0 : kprev;
+                    const int64_t kmax = ri.n_eff - 2;
+                    while (k < kmax) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) v[q] = (k + 1 + q <= kmax + 1) ? s[k + 1 + q] : __int_as_float(0x7f800000);
+                        int cnt = 0; bool run = true;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { run = run && ((double)v[q] <= t); cnt += run ? 1 : 0; }
+                        k += cnt;
+                        if (cnt < 8) break;
+                    }
+                    if (k > kmax) k = kmax;
+                }
+                kprev = k;
+                pos_at(k, t, x, y);
+            }
+            long long xi = vs::round_half_even(x), yi = vs::round_half_even(y);
+            A.sx[g] = x; A.sy[g] = y; A.rank[g] = (unsigned)r;
+            bool in = xi >= 0 && yi >= 0 && xi < W && yi < H;
+            A.xi[g] = (int)xi; A.yi[g] = (int)yi; A.inc[g] = in ? 1 : 0;
+            if (pixbits && in) {       // the canvas is read at sample pixels only (k_caps_stamp_bits): mark the pixel, give it its "never stamped" value
+                unsigned long long* wp = &pixbits[(size_t)yi * Wq + (xi >> 6)]; const unsigned long long bit = 1ULL << (xi & 63);
+                if (!(*wp & bit) && !(atomicOr(wp, bit) & bit)) firstseq[(size_t)yi * W + xi] = 0xffffffffu;      // whoever sets the bit initialises the pixel: one write per distinct pixel, not per sample
+            }
+            if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
+            // distance to the predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
+            if (j == 0) A.dprev[g] = 0.0;
+            else if (u > 0) A.dprev[g] = vs::norm2_f64(x - px, y - py);
+            else { x0 = x; y0 = y; }                       // the predecessor is the previous thread's last sample: after the barrier
+            px = x; py = y; xl = x; yl = y;
+            j++;
+        }
+        if (j0 > 0 && threadIdx.x == 0) {                  // the first thread of a block computes its predecessor again
+            // (the loop above has moved on: look the polyline of sample g0 up again)
+            int64_t r2 = sample_rank(sbase, info, ord, h0.x + 1, (int64_t)h1.x + 1, g0);
+            const unsigned i2 = ord[r2]; cu = src.cur(i2); s = cum + cumoff[i2]; ri = info[i2];
+            double qx, qy;
+            if (ri.pass) { const int2 q = cu.at(j0 - 1); qx = (double)(float)q.x; qy = (double)(float)q.y; }
+            else { const double t = (double)sample_t(j0 - 1, step); pos_at(sample_seg(s, ri.n_eff, t, -1, ri.n_eff - 2), t, qx, qy); }
+            A.dprev[g0] = vs::norm2_f64(x0 - qx, y0 - qy);
+        }
     }
-    if (ckeys) { ckeys[g] = cell_key32((long long)floor(__dmul_rn(x, inv_cell)), (long long)floor(__dmul_rn(y, inv_cell))); cvals[g] = g; }
-    // distance to the predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147): the predecessor is the
-    // previous thread's sample; the first thread of a block computes it again
-    if (threadIdx.x == 0 && j > 0) { double px, py; pos(j - 1, -1, ri.n_eff - 2, px, py); A.dprev[g] = vs::norm2_f64(x - px, y - py); }
-    }
-    shx[threadIdx.x] = x; shy[threadIdx.x] = y;
+    shx[threadIdx.x] = xl; shy[threadIdx.x] = yl;
     __syncthreads();
-    if (act && threadIdx.x > 0) A.dprev[g] = j > 0 ? vs::norm2_f64(x - shx[threadIdx.x - 1], y - shy[threadIdx.x - 1]) : 0.0;
-    if (act && threadIdx.x == 0 && j == 0) A.dprev[g] = 0.0;
+    if (act && j0 > 0 && threadIdx.x > 0) A.dprev[g0] = vs::norm2_f64(x0 - shx[threadIdx.x - 1], y0 - shy[threadIdx.x - 1]);
 }
 
 // distance of every sample to its predecessor on the same polyline, exactly as the tail bookkeeping evaluates it (08:141,147)
@@ -1545,7 +1597,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 HIPC(c, hipMemsetAsync(pixbits, 0, (size_t)Wq * H * 8, LN(c).stream));
             } else HIPC(c, hipMemsetAsync(firstseq, 0xff, (size_t)W * H * 4, LN(c).stream));
             hipLaunchKernelGGL(k_sample_hints, dim3(cdiv(nb, 256)), dim3(256), 0, LN(c).stream, cumoff, cum, info, ord, sbase, nk, MS, step, nb, hints);
-            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(nb), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints, pixbits, Wq, firstseq); }); }
+            { ProfScope ps(c, "k_samples"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_samples<decltype(sv)>, dim3(cdiv(nb, 4)), dim3(256), 0, LN(c).stream, sv, cumoff, cum, info, ord, sbase, nk, MS, step, W, H, A, inv, (unsigned*)nullptr, (unsigned*)nullptr, hints, (unsigned)nb, pixbits, Wq, firstseq); }); }
             tick("samples");
             // ---- A3
             {
