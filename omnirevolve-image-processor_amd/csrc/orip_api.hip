@@ -45,7 +45,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
     for (auto& l : c->ln) {
         l.tmpE.release(); l.tmpF.release(); l.flags.release(); l.canvas.release(); l.pixbits.release();
         for (auto& v : l.vtmp) v.release();
-        for (DBuf* b : {&l.pf08.feat, &l.pf08.info, &l.pf08.cum, &l.pf08.ord}) b->release();
+        for (DBuf* b : {&l.pf08.seg, &l.pf08.feat, &l.pf08.info, &l.pf08.cum, &l.pf08.ord}) b->release();
         if (l.ev0) hipEventDestroy(l.ev0);
         if (l.ev1) hipEventDestroy(l.ev1);
         if (l.ev2) hipEventDestroy(l.ev2);

@@ -110,6 +110,7 @@ struct LaneRes {
     struct Prefetch08 {
         bool valid = false; uint64_t tag = 0; int64_t n = 0; int64_t tot_f = 0; double step = 0;
         const int64_t* src_off = nullptr;   // offsets of the list it was computed on (device): both readings of polyline i keep their cumulative lengths at src_off[i]
+        DBuf seg;                      // float32 length of every segment of the list (k_cumlen_long2 forward -> reversed reading, perimeter sums)
         DBuf feat, info, cum, ord;     // PolyFeat[n] + reversed perimeters float[n]; RsInfo[2n]: forward at i, reversed at n + i; cum: forward readings, then (tot_f on) reversed
     } pf08;
 };

@@ -176,11 +176,28 @@ __device__ __forceinline__ float pairwise_leaf_g8_rev(const int32_t* xy, int64_t
     for (int64_t i = lim; i < n; i++) r += el(i);
     return r;
 }
+// the same leaves over STORED segment lengths (sl[k] = float32 length of segment k; prefetch08: k_cumlen_long2 leaves them behind)
+__device__ __forceinline__ float pairwise_leaf_f(const float* sl, int64_t s, int64_t n, int j) {
+    const int64_t lim = n - (n % 8);
+    float r = sl[s + j];
+    for (int64_t i = 8 + j; i < lim; i += 8) r += sl[s + i];
+    r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+    for (int64_t i = lim; i < n; i++) r += sl[s + i];
+    return r;
+}
+__device__ __forceinline__ float pairwise_leaf_f_rev(const float* sl, int64_t ns, int64_t s, int64_t n, int j) {
+    const int64_t lim = n - (n % 8);
+    float r = sl[ns - 1 - (s + j)];
+    for (int64_t i = 8 + j; i < lim; i += 8) r += sl[ns - 1 - (s + i)];
+    r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+    for (int64_t i = lim; i < n; i++) r += sl[ns - 1 - (s + i)];
+    return r;
+}
 #define ORIP_PF_MARGIN 132      // points staged on either side of a turn's 2048: a leaf has at most 128 elements and owns a multiple of 64 of the turn
-template <class Src>
+template <class Src, bool FROM_SEG = false>
 __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_polys, int what,
                                                              PolyFeat* __restrict__ out, float* __restrict__ leafbuf, const unsigned* __restrict__ order,
-                                                             float* __restrict__ per_rev, float* __restrict__ leafbuf_rev) {
+                                                             float* __restrict__ per_rev, float* __restrict__ leafbuf_rev, const float* __restrict__ seg = nullptr) {
     __shared__ int rx0[256], rx1[256], ry0[256], ry1[256];
     __shared__ double rarc[256];
     __shared__ float part[2 << ORIP_PW_DEPTH];
@@ -247,10 +264,17 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
             // The points of the NEXT turn are requested before the leaves of this turn are summed and only land in LDS after them.
             constexpr int NX = (2048 + 2 * ORIP_PF_MARGIN + 255) / 256;
             int2 nxt[NX];
+            // FROM_SEG: the stretch holds the stored LENGTHS of the segments [lo, hi - 1) instead of the points [lo, hi) (the bounding box is in place already)
+            const float* sgp = FROM_SEG ? seg + src.off[i] : nullptr;
+            float* stagef = reinterpret_cast<float*>(stage);
             auto request = [&](int64_t r0) {
                 const int64_t lo = max((int64_t)0, r0 - ORIP_PF_MARGIN), hi = min(n, r0 + 2048 + ORIP_PF_MARGIN);
 #pragma unroll
-                for (int u = 0; u < NX; u++) { const int64_t q = lo + tid + 256 * u; nxt[u] = q < hi ? P2(q) : make_int2(0, 0); }
+                for (int u = 0; u < NX; u++) {
+                    const int64_t q = lo + tid + 256 * u;
+                    if (FROM_SEG) nxt[u].x = q < hi - 1 ? __float_as_int(sgp[q]) : 0;
+                    else nxt[u] = q < hi ? P2(q) : make_int2(0, 0);
+                }
             };
             request(0);
             for (int64_t r0 = 0; r0 < n; r0 += 32 * 64) {      // (the last turn may hold points only: the bounding box wants them all)
@@ -259,7 +283,8 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
 #pragma unroll
                 for (int u = 0; u < NX; u++) {
                     const int64_t q = lo + tid + 256 * u;
-                    if (q < hi) {
+                    if (FROM_SEG) { if (q < hi - 1) stagef[tid + 256 * u] = __int_as_float(nxt[u].x); }
+                    else if (q < hi) {
                         stage[tid + 256 * u] = nxt[u];
                         if (q >= r0 && q < r0 + 2048) { x0 = min(x0, nxt[u].x); x1 = max(x1, nxt[u].x); y0 = min(y0, nxt[u].y); y1 = max(y1, nxt[u].y); }
                     }
@@ -267,6 +292,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                 __syncthreads();
                 if (r0 + 32 * 64 < n) request(r0 + 32 * 64);
                 const int32_t* sp = reinterpret_cast<const int32_t*>(stage) - 2 * lo;        // sp[2 * k] = x of point k
+                const float* sf = stagef - lo;                                               // sf[k] = length of segment k
                 auto leaf_of = [&](int64_t pm, int64_t& s, int64_t& len) {                   // the leaf of numpy's tree over ns elements that holds element pm
                     s = 0; len = ns;
                     while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
@@ -275,7 +301,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                 if (pm < ns) {
                     int64_t s, len; leaf_of(pm, s, len);
                     if (((s + 63) >> 6) << 6 == pm) {   // every multiple of 64 lies in exactly one leaf; its first one owns the leaf
-                        float v = (what & 1) ? pairwise_leaf_g8<0>(sp, s, len, j) : pairwise_leaf_g8<1>(sp, s, len, j);
+                        float v = FROM_SEG ? pairwise_leaf_f(sf, s, len, j) : ((what & 1) ? pairwise_leaf_g8<0>(sp, s, len, j) : pairwise_leaf_g8<1>(sp, s, len, j));
                         if (j == 0) ls[pm >> 6] = v;
                     }
                 }
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                     if (pmr < ihi) {
                         int64_t s, len; leaf_of(pmr, s, len);
                         if (((s + 63) >> 6) << 6 == pmr) {
-                            float v = pairwise_leaf_g8_rev(sp, ns, s, len, j);
+                            float v = FROM_SEG ? pairwise_leaf_f_rev(sf, ns, s, len, j) : pairwise_leaf_g8_rev(sp, ns, s, len, j);
                             if (j == 0) lsR[pmr >> 6] = v;
                         }
                     }
@@ -330,26 +356,36 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
             if (tid < s) { rx0[tid] = min(rx0[tid], rx0[tid + s]); rx1[tid] = max(rx1[tid], rx1[tid + s]); ry0[tid] = min(ry0[tid], ry0[tid + s]); ry1[tid] = max(ry1[tid], ry1[tid + s]); rarc[tid] += rarc[tid + s]; }
             __syncthreads();
         }
-        if (tid == 0) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; f.arc = rarc[0]; f.per = per; out[i] = f; if (want_rev) per_rev[i] = perR; }
+        if (tid == 0) {
+            if (!FROM_SEG) { f.x0 = rx0[0]; f.x1 = rx1[0]; f.y0 = ry0[0]; f.y1 = ry1[0]; }       // FROM_SEG: the box came with f (k_cumlen_long2 wrote it)
+            f.arc = rarc[0]; f.per = per; out[i] = f; if (want_rev) per_rev[i] = perR;
+        }
         __syncthreads();
     }
 }
 // features of every polyline of a list: short ones one lane each, long ones one block each
+// the long polylines' part of vfeatures_src; seg != nullptr: their perimeters from stored segment lengths (what == 1 | 16 [| 32]; bounding boxes already in feat)
+template <class Src>
+static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev, const float* seg = nullptr) {
+    if (n == 0 || total <= ORIP_LONG_POLY) return 0;
+    const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
+    HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) * ((what & 32) ? 2 : 1) + (size_t)n * 16 + 64));
+    float* leafbuf = LN(c).vtmp[11].as<float>(); float* leafbuf_rev = (what & 32) ? leafbuf + nleaf : nullptr;
+    unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf * ((what & 32) ? 2 : 1)); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
+    hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
+    ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
+    ProfScope ps(c, "k_poly_features_long");
+    if (seg) hipLaunchKernelGGL((k_poly_features_long<Src, true>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, seg);
+    else hipLaunchKernelGGL((k_poly_features_long<Src, false>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, (const float*)nullptr);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
 template <class Src>
 static int vfeatures_src(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev = nullptr) {
     if (n == 0) return 0;
     if (!per_rev) what &= ~32;
     hipLaunchKernelGGL(k_poly_features<Src>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, src, n, what, feat, per_rev);
-    if (total > ORIP_LONG_POLY) {
-        const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
-        HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) * ((what & 32) ? 2 : 1) + (size_t)n * 16 + 64));
-        float* leafbuf = LN(c).vtmp[11].as<float>(); float* leafbuf_rev = (what & 32) ? leafbuf + nleaf : nullptr;
-        unsigned* kin = reinterpret_cast<unsigned*>(leafbuf + nleaf * ((what & 32) ? 2 : 1)); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* vout = vin + n;
-        hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
-        ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
-        ProfScope ps(c, "k_poly_features_long");
-        hipLaunchKernelGGL(k_poly_features_long<Src>, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev);
-    }
+    ORIP_TRY(vfeatures_long(c, src, n, total, what, feat, per_rev));
     HIPC(c, hipGetLastError());
     return 0;
 }

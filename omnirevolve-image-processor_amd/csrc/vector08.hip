@@ -186,9 +186,10 @@ __device__ __forceinline__ int2 lane_succ(const int2 v, const int2 last, int lan
     return r;
 }
 template <class Src, bool CHAIN>
-__global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord) {
+__global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
+                                                     int dir0, float* __restrict__ seg, PolyFeat* __restrict__ bb) {
     const int lane = threadIdx.x;
-    const bool rev = blockIdx.y == 1;      // blockIdx.y picks the reading direction: one wave per polyline and direction
+    const bool rev = ((blockIdx.y + (unsigned)dir0) & 1u) != 0;      // the reading direction: one wave per polyline and direction
     for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
         const int64_t i = ord[rr];
         RsInfo r = info[rev ? n_polys + i : i];
@@ -196,31 +197,52 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
         auto cu = src.cur(i); const int64_t nfull = src.len(i);
         float* s = cum + (rev ? rev_off : 0) + src.off[i];
         const int64_t ns = r.n_eff - 1;                                             // segments; points 0 .. ns of this reading
+        // prefetch08 (seg != nullptr): the forward reading leaves the float32 length of EVERY segment of the polyline in seg (and the bounding box of
+        // its open view in bb) -- the reversed reading and the perimeter sums of stage 08 then read 4 bytes per segment instead of turning
+        // (polyline, index) into a point again (~25 instructions; the launches are bound by instruction issue)
+        float* sg = seg ? seg + src.off[i] : nullptr;
+        const bool from_seg = rev && sg && info[i].n_eff > ORIP_LONG_CUM;           // (the forward wave of this polyline has run: an earlier launch)
+        const int64_t nall = (sg && !rev) ? (nfull - 1 > ns ? nfull - 1 : ns) : ns; // segments whose length is computed here
+        const int64_t vn = (bb && !rev) ? bb[i].n : 0;                              // bounding box over the points [0, vn)
+        int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
         float acc = 0.f; unsigned cE = 0u, cM = 0u;
         if (lane == 0) s[0] = 0.f;
-        // A turn is 4 windows of 64 segment lengths.  Every point is fetched ONCE (the cursor call is ~25 instructions, and the launch is bound by
-        // instruction issue: 2.8e8 points per heavy layer and direction): the far end of segment k is the point in the next lane, the far end of a
-        // window's last segment the first point of the next window, of a turn's last segment one extra point.  The points of the next turn are
-        // requested before this turn's sums run.
+        // A turn is 4 windows of 64 segment lengths.  Every point is fetched ONCE: the far end of segment k is the point in the next lane, the far end of a
+        // window's last segment the first point of the next window, of a turn's last segment one extra point.  The points (or stored lengths) of the
+        // next turn are requested before this turn's sums run.
         auto P = [&](int64_t k) { return cu.at(rev ? nfull - 1 - k : k); };
-        auto request = [&](int64_t base, int2 (&p)[5]) {
+        auto request = [&](int64_t base, int2 (&p)[5], float (&fl)[4]) {
+            if (from_seg) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k <= ns ? P(k) : make_int2(0, 0); }
-            p[4] = base + 256 <= ns ? P(base + 256) : make_int2(0, 0);
+                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; fl[w] = k < ns ? sg[nfull - 2 - k] : 0.f; }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k <= nall ? P(k) : make_int2(0, 0); }
+                p[4] = base + 256 <= nall ? P(base + 256) : make_int2(0, 0);
+            }
         };
-        auto lengths = [&](int64_t base, const int2 (&p)[5], float (&sl)[4]) {
+        auto lengths = [&](int64_t base, const int2 (&p)[5], const float (&fl)[4], float (&sl)[4]) {
+            if (from_seg) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) sl[w] = fl[w];
+                return;
+            }
 #pragma unroll
             for (int w = 0; w < 4; w++) {
+                const int64_t k = base + 64 * w + lane;
                 const int2 nx0 = w < 3 ? make_int2(__builtin_amdgcn_readlane(p[w + 1].x, 0), __builtin_amdgcn_readlane(p[w + 1].y, 0)) : p[4];
                 const int2 b2 = lane_succ(p[w], nx0, lane);
                 float dx = (float)b2.x - (float)p[w].x, dy = (float)b2.y - (float)p[w].y; float qx = dx * dx, qy = dy * dy;
-                sl[w] = (base + 64 * w + lane < ns) ? sqrtf(qx + qy) : 0.f;            // seg_len_f32; beyond the last segment: +0
+                const float L = sqrtf(qx + qy);                                        // seg_len_f32
+                if (sg && k < nall) sg[k] = L;
+                sl[w] = k < ns ? L : 0.f;                                              // beyond the last segment of this reading: +0
+                if (k < vn) { bx0 = min(bx0, p[w].x); bx1 = max(bx1, p[w].x); by0 = min(by0, p[w].y); by1 = max(by1, p[w].y); }
             }
         };
-        int2 rp[5]; float cur[4];
-        request(0, rp); lengths(0, rp, cur);
-        for (int64_t base = 0; base < ns; base += 256) {
-            request(base + 256, rp);
+        int2 rp[5]; float rf[4] = {0.f, 0.f, 0.f, 0.f}; float cur[4];
+        request(0, rp, rf); lengths(0, rp, rf, cur);
+        for (int64_t base = 0; base < nall; base += 256) {
+            request(base + 256, rp, rf);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int64_t k = base + 64 * w + lane;
@@ -235,7 +257,11 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
                 } else { pv = cum_window(cur[w], lane, cE, cM); acc = cum_state_value(cE, cM); }
                 if (k < ns) s[k + 1] = pv;
             }
-            lengths(base + 256, rp, cur);
+            lengths(base + 256, rp, rf, cur);
+        }
+        if (vn > 0) {
+            for (int o = 32; o > 0; o >>= 1) { bx0 = min(bx0, __shfl_xor(bx0, o, 64)); bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64)); }
+            if (lane == 0) { bb[i].x0 = bx0; bb[i].x1 = bx1; bb[i].y0 = by0; bb[i].y1 = by1; }
         }
         if (lane == 0) { rs_finish(r, acc, r.n_eff, step); info[rev ? n_polys + i : i] = r; }
     }
@@ -1432,21 +1458,29 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
     HIPC(c, F.info.ensure((size_t)2 * n * sizeof(RsInfo) + 64));
     HIPC(c, F.cum.ensure((size_t)2 * total * 4 + 64));
     HIPC(c, F.ord.ensure((size_t)n * 16 + 64));
+    HIPC(c, F.seg.ensure((size_t)total * 4 + 64));
     {
         StreamSwap sw(LN(c));                       // LN(c).stream is the side stream from here to the end of the block
         HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev2, 0));      // stage 07's features (feat07) and its use of the shared scratch end here (vreorder)
         PolyFeat* ff = F.feat.as<PolyFeat>(); float* per_rev = reinterpret_cast<float*>(ff + n); RsInfo* inf = F.info.as<RsInfo>(); float* cum = F.cum.as<float>();
         VSrc sS; ORIP_TRY(vsrc_of(c, S, sS));
-        // A2 first (the long serial chains): cumulative lengths of both readings; long polylines longest first
+        // per-polyline fields first (open view, end points; bounding box and perimeters of the short ones): one thread per polyline
+        hipLaunchKernelGGL(k_poly_features<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, n, 1 | 16 | 32, ff, per_rev);
+        // A2 (the long polylines): cumulative lengths of both readings, longest first.  The forward reading fetches the points (once each) and leaves
+        // every segment's float32 length in F.seg and the open view's bounding box in ff; the reversed reading and the perimeter sums (A0 / A1,
+        // forwards and backwards) then read 4 bytes per segment instead of turning (polyline, index) into a point again.
         unsigned* kin = F.ord.as<unsigned>(); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* ordl = vin + n;
+        float* seg = F.seg.as<float>();
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
         if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
-            if (chain) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl);
-            else hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), dim3((unsigned)std::min<int64_t>(n, 8192), 2), dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl); }
-        // A0 / A1: bounding box and numpy perimeter of the opened polyline, read forwards and backwards, in one pass over the points
-        ORIP_TRY(vfeatures_src(c, sS, n, total, 1 | 16 | 32, ff, per_rev));
+            const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 1);
+            for (int dir = 0; dir < 2; dir++) {          // forward, then (reading what forward stored) reversed
+                if (chain) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
+                else hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
+            } }
+        ORIP_TRY(vfeatures_long(c, sS, n, total, 1 | 16 | 32, ff, per_rev, seg));
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream));
     }
@@ -1564,8 +1598,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
         if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
             ORIP_WITH_SRC(c, kept0.p, sv, {
-                if (chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord);
-                else hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord); }); }
+                if (chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr);
+                else hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }); }
         }
         tick("cumlen");
         HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));
