@@ -69,7 +69,9 @@ struct PolyFeat {
     uint8_t closed;             // first == last on the ORIGINAL polyline (n >= 2)
 };
 
-#define ORIP_LONG_POLY 512
+// (stage 08's prefetch takes the perimeters of polylines above this from the segment lengths k_cumlen_long2 stores for readings above ORIP_LONG_CUM = 128
+// points; a reading is at most two points shorter than the open view counted here, so the threshold must stay above 130)
+#define ORIP_LONG_POLY 192
 // ---- where a list's points come from (vsrc.h): explicit array or the layer's walk records ----
 static inline ESrc esrc_of(const DPolys& P) { return ESrc{P.off.as<int64_t>(), reinterpret_cast<const int2*>(P.pts.p)}; }
 static int vsrc_of(orip_ctx* c, const DPolys& P, VSrc& out) {
