@@ -413,7 +413,7 @@ __global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ e
     __shared__ unsigned long long wbest[16];
     __shared__ int cxs, cys;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 1024) used[i] = (i == seed);
+    for (int i = tid; i < n; i += (int)blockDim.x) used[i] = (i == seed);
     if (tid == 0) {
         order[0] = seed; flips[0] = 0;
         NNEnds e = ends[seed];
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ e
     for (int step = 1; step < n; step++) {
         const int cx = cxs, cy = cys;
         unsigned long long best = ~0ULL;
-        for (int i = tid; i < n; i += 1024) {
+        for (int i = tid; i < n; i += (int)blockDim.x) {
             if (used[i]) continue;
             NNEnds e = ends[i];
             float ds = nn_d2(e.sx, e.sy, cx, cy);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_greedy_nn(const NNEnds* __restrict__ e
         __syncthreads();
         if (tid == 0) {
             unsigned long long b = wbest[0];
-            for (int w = 1; w < 16; w++) if (wbest[w] < b) b = wbest[w];
+            for (int w = 1; w < (int)(blockDim.x >> 6); w++) if (wbest[w] < b) b = wbest[w];
             int bi = (int)(b & 0xffffffffu);
             NNEnds e = ends[bi];
             float ds = nn_d2(e.sx, e.sy, cx, cy), de = nn_d2(e.ex, e.ey, cx, cy);
@@ -1364,8 +1364,11 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
             }
             if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
         }
-        if (lds_ok) hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, d_seed, 1, grid_ok ? 2 : 0, r07, order, flips);   // with a grid candidate: only when the grid bowed out
-        hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(1024), 0, LN(c).stream, ends, (int)n, d_seed, 0, lds_ok ? 1 : 0, r07, used, order, flips);
+        // Behind the grid kernel only ONE more launch, and a light one (256 threads, no dynamic LDS): a kernel that merely checks its flag and
+        // returns still waits for a CU with room for its whole workgroup -- 0.5 ms for 1024 threads or 150 KB of LDS next to the other layers' work.
+        // The grid kernel bows out for coordinates beyond 15 bits only (never on a canvas below 32768 px): the global-memory kernel takes those.
+        if (lds_ok && !grid_ok) hipLaunchKernelGGL(k_greedy_nn_lds, dim3(1), dim3(1024), lds, LN(c).stream, ends, (int)n, d_seed, 1, 0, r07, order, flips);
+        hipLaunchKernelGGL(k_greedy_nn, dim3(1), dim3(lds_ok ? 256 : 1024), 0, LN(c).stream, ends, (int)n, d_seed, 0, grid_ok ? 3 : (lds_ok ? 1 : 0), r07, used, order, flips);
     }
     if (under_greedy) ORIP_TRY(under_greedy(c, hook_arg, src, feat));
     hipLaunchKernelGGL(k_desc_from_order, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off.as<int64_t>(), order, flips, n, 0, feat, desc);
