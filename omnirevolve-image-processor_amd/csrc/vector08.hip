@@ -775,27 +775,42 @@ __global__ __launch_bounds__(256) void k_cell_keys(SampleArrs A, unsigned MS, do
 __global__ __launch_bounds__(256) void k_accept_pre(SampleArrs A, const unsigned* __restrict__ sbase, const unsigned* __restrict__ npop, unsigned MS,
                                                      const unsigned* __restrict__ firstseq, int W, int2* __restrict__ spt, uint8_t* __restrict__ sflag,
                                                      unsigned* __restrict__ surv, unsigned* __restrict__ n_surv, unsigned long long* __restrict__ work) {
-    unsigned g = blockIdx.x * 256 + threadIdx.x;
-    bool need = false; unsigned mynp = 0;
-    if (g < MS) {
-        unsigned r = A.rank[g], b = sbase[r], j = g - b;
-        bool ok = A.inc[g] != 0;
-        const unsigned np = npop[g];
-        unsigned limit = b + np;         // own samples with global index < limit have been popped (hashed + stamped)
-        if (ok && firstseq[(size_t)A.yi[g] * W + A.xi[g]] < limit) ok = false;
-        spt[g] = make_int2((int)A.sx[g], (int)A.sy[g]);
-        sflag[g] = (ok ? 1 : 0) | (j == 0 ? 2 : 0);
-        need = ok && np > 0; mynp = need ? np : 0u;
+    // four samples per thread, 256 apart (as k_caps_insert: the chains rank -> base and pixel -> canvas word are waited for, not the bandwidth)
+    constexpr int S = 4;
+    const unsigned g0 = blockIdx.x * (256 * S) + threadIdx.x;
+    unsigned g[S], bb[S], np[S]; int xi[S], yi[S]; bool ok[S], on[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) { g[u] = g0 + 256u * u; on[u] = g[u] < MS; bb[u] = on[u] ? A.rank[g[u]] : 0u; }
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        np[u] = 0; xi[u] = 0; yi[u] = 0; ok[u] = false;
+        if (on[u]) { bb[u] = sbase[bb[u]]; ok[u] = A.inc[g[u]] != 0; np[u] = npop[g[u]]; xi[u] = A.xi[g[u]]; yi[u] = A.yi[g[u]]; }
     }
-    const unsigned long long m = __ballot(need);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned long long wsum = mynp;                    // popped own samples the survivors of this wave have to be compared with
-        for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
-        unsigned base = 0;
-        if (lane == 0) { base = atomicAdd(n_surv, (unsigned)__popcll(m)); atomicAdd(work, wsum); }
-        base = (unsigned)__shfl((int)base, 0, 64);
-        if (need) surv[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = g;
+    unsigned fs[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) fs[u] = (on[u] && ok[u]) ? firstseq[(size_t)yi[u] * W + xi[u]] : 0xffffffffu;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+        bool need = false; unsigned mynp = 0;
+        if (on[u]) {
+            const unsigned j = g[u] - bb[u];
+            const unsigned limit = bb[u] + np[u];         // own samples with global index < limit have been popped (hashed + stamped)
+            bool k = ok[u];
+            if (k && fs[u] < limit) k = false;
+            spt[g[u]] = make_int2((int)A.sx[g[u]], (int)A.sy[g[u]]);
+            sflag[g[u]] = (k ? 1 : 0) | (j == 0 ? 2 : 0);
+            need = k && np[u] > 0; mynp = need ? np[u] : 0u;
+        }
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            unsigned long long wsum = mynp;                    // popped own samples the survivors of this wave have to be compared with
+            for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+            unsigned base = 0;
+            if (lane == 0) { base = atomicAdd(n_surv, (unsigned)__popcll(m)); atomicAdd(work, wsum); }
+            base = (unsigned)__shfl((int)base, 0, 64);
+            if (need) surv[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = g[u];
+        }
     }
 }
 // _PointHash.near without the hash: a survivor is compared with ALL popped samples of its own polyline, 64 at a time.  Equal to the
@@ -1705,7 +1720,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 unsigned long long* d_work = reinterpret_cast<unsigned long long*>(LN(c).flags.as<unsigned>() + 124);
                 HIPC(c, hipMemsetAsync(d_ns, 0, 4, LN(c).stream));
                 HIPC(c, hipMemsetAsync(d_work, 0, 8, LN(c).stream));
-                { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept_pre, dim3(cdiv(MS, 256)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, firstseq, W, spt, sflag, surv, d_ns, d_work); }
+                { ProfScope ps(c, "k_accept"); hipLaunchKernelGGL(k_accept_pre, dim3(cdiv(MS, 1024)), dim3(256), 0, LN(c).stream, A, sbase, npop, MS, firstseq, W, spt, sflag, surv, d_ns, d_work); }
                 unsigned long long h_work = 0; ORIP_TRY(vread(c, &h_work, d_work));
                 const double R2 = P.col_rad * P.col_rad;
                 // without the hash when it gives the hash's answer (cell >= radius) and costs less than sorting every sample into buckets
