@@ -195,6 +195,29 @@ __device__ __forceinline__ float pairwise_leaf_f_rev(const float* sl, int64_t ns
     for (int64_t i = lim; i < n; i++) r += sl[ns - 1 - (s + i)];
     return r;
 }
+// All leaves of numpy's pairwise trees of all long polylines in ONE launch, from stored segment lengths (prefetch08): 8 lanes per slot of the leaf table
+// (slot (off[i] >> 6) + 2 i + m belongs to the multiple 64 m of polyline i; the leaf that holds element 64 m owns it when 64 m is its first multiple of 64).
+// The same leaf shape serves the forward sum and the sum over the reversed sequence (element i' of the reversed polyline = forward segment ns - 1 - i').
+// k_poly_features_long then only combines the leaves (what & 64): with one block per polyline staging the lengths through LDS the launch was as long as
+// ~7 rounds of 186 k-element polylines at five blocks per CU.
+__global__ __launch_bounds__(256) void k_perim_leaves_seg(const int64_t* __restrict__ off, int64_t n_polys, const PolyFeat* __restrict__ feat, const float* __restrict__ seg,
+                                                          float* __restrict__ leafbuf, float* __restrict__ leafbuf_rev, int64_t nslots) {
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; const int j = threadIdx.x & 7;
+    if (q >= nslots) return;
+    int64_t lo = 0, hi = n_polys - 1;                     // polyline of slot q: the last i with (off[i] >> 6) + 2 i <= q
+    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((off[mid] >> 6) + 2 * mid <= q) lo = mid; else hi = mid - 1; }
+    const int64_t i = lo, n = feat[i].n;
+    if (n <= ORIP_LONG_POLY) return;
+    const int64_t ns = n - 1, pm = (q - ((off[i] >> 6) + 2 * i)) << 6;
+    if (pm >= ns) return;
+    int64_t s = 0, len = ns;                              // the leaf of the tree over ns elements that holds element pm
+    while (len > 128) { int64_t n2 = len / 2; n2 -= n2 % 8; if (pm < s + n2) len = n2; else { s += n2; len -= n2; } }
+    if ((((s + 63) >> 6) << 6) != pm) return;
+    const float* sl = seg + off[i];
+    const float v = pairwise_leaf_f(sl, s, len, j);
+    if (j == 0) leafbuf[q] = v;
+    if (leafbuf_rev) { const float r = pairwise_leaf_f_rev(sl, ns, s, len, j); if (j == 0) leafbuf_rev[q] = r; }
+}
 #define ORIP_PF_MARGIN 132      // points staged on either side of a turn's 2048: a leaf has at most 128 elements and owns a multiple of 64 of the turn
 template <class Src, bool FROM_SEG = false>
 __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_polys, int what,
@@ -278,8 +301,8 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
                     else nxt[u] = q < hi ? P2(q) : make_int2(0, 0);
                 }
             };
-            request(0);
-            for (int64_t r0 = 0; r0 < n; r0 += 32 * 64) {      // (the last turn may hold points only: the bounding box wants them all)
+            if (!(what & 64)) request(0);
+            for (int64_t r0 = 0; r0 < n && !(what & 64); r0 += 32 * 64) {      // (the last turn may hold points only: the bounding box wants them all; what & 64: the leaf sums are in place, k_perim_leaves_seg)
                 const int64_t lo = max((int64_t)0, r0 - ORIP_PF_MARGIN), hi = min(n, r0 + 2048 + ORIP_PF_MARGIN);       // points [lo, hi)
                 __syncthreads();
 #pragma unroll
@@ -377,7 +400,10 @@ static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total,
     hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
     ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
     ProfScope ps(c, "k_poly_features_long");
-    if (seg) hipLaunchKernelGGL((k_poly_features_long<Src, true>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, seg);
+    if (seg) {
+        hipLaunchKernelGGL(k_perim_leaves_seg, dim3((unsigned)cdiv((int64_t)nleaf * 8, 256)), dim3(256), 0, LN(c).stream, src.off, n, feat, seg, leafbuf, leafbuf_rev, (int64_t)nleaf);
+        hipLaunchKernelGGL((k_poly_features_long<Src, true>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what | 64, feat, leafbuf, vout, per_rev, leafbuf_rev, seg);
+    }
     else hipLaunchKernelGGL((k_poly_features_long<Src, false>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, (const float*)nullptr);
     HIPC(c, hipGetLastError());
     return 0;

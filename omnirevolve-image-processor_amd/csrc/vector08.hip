@@ -146,11 +146,14 @@ __device__ __forceinline__ float cum_state_value(unsigned E, unsigned M) { retur
 // cum / info of the reversed reading live `rev_off` floats / `n_polys` entries behind the forward ones.
 template <class Src>
 __global__ __launch_bounds__(128) void k_cumlen2(Src src, const PolyFeat* __restrict__ feat07, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_polys) return;
+    // one thread per polyline AND reading direction (the first n_polys threads read forwards): the launch is a few dozen blocks whose time is the longest
+    // thread's loop, so two loops in a row per thread were twice that
+    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= 2 * n_polys) return;
+    const int64_t i = gi < n_polys ? gi : gi - n_polys; const int dir0 = gi < n_polys ? 0 : 1;
     auto cu = src.cur(i); const int64_t nfull = src.len(i);
     const bool closed = feat07[i].closed != 0;
-    for (int dir = 0; dir < 2; dir++) {
+    for (int dir = dir0; dir <= dir0; dir++) {
         int64_t n = (dir == 0 && closed && nfull > 0) ? nfull - 1 : nfull;         // the view: opened forward, whole reversed
         float* s = cum + (dir ? rev_off : 0) + src.off[i];
         auto P = [&](int64_t k) { return dir ? cu.at(nfull - 1 - k) : cu.at(k); };
@@ -1488,7 +1491,7 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
         float* seg = F.seg.as<float>();
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
-        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
+        { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(2 * n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
         if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
             const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 1);
             for (int dir = 0; dir < 2; dir++) {          // forward, then (reading what forward stored) reversed
