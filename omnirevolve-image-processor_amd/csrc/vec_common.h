@@ -202,11 +202,18 @@ __device__ __forceinline__ float pairwise_leaf_f_rev(const float* sl, int64_t ns
 // ~7 rounds of 186 k-element polylines at five blocks per CU.
 __global__ __launch_bounds__(256) void k_perim_leaves_seg(const int64_t* __restrict__ off, int64_t n_polys, const PolyFeat* __restrict__ feat, const float* __restrict__ seg,
                                                           float* __restrict__ leafbuf, float* __restrict__ leafbuf_rev, int64_t nslots) {
+    __shared__ int64_t i_first;
     const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; const int j = threadIdx.x & 7;
+    if (threadIdx.x == 0) {                               // polyline of the block's first slot: the last i with (off[i] >> 6) + 2 i <= q; the other 31 slots walk on from it
+        int64_t lo = 0, hi = n_polys - 1;
+        while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((off[mid] >> 6) + 2 * mid <= q) lo = mid; else hi = mid - 1; }
+        i_first = lo;
+    }
+    __syncthreads();
     if (q >= nslots) return;
-    int64_t lo = 0, hi = n_polys - 1;                     // polyline of slot q: the last i with (off[i] >> 6) + 2 i <= q
-    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((off[mid] >> 6) + 2 * mid <= q) lo = mid; else hi = mid - 1; }
-    const int64_t i = lo, n = feat[i].n;
+    int64_t i = i_first;
+    while (i + 1 < n_polys && (off[i + 1] >> 6) + 2 * (i + 1) <= q) i++;
+    const int64_t n = feat[i].n;
     if (n <= ORIP_LONG_POLY) return;
     const int64_t ns = n - 1, pm = (q - ((off[i] >> 6) + 2 * i)) << 6;
     if (pm >= ns) return;
