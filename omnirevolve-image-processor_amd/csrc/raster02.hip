@@ -395,6 +395,8 @@ __global__ __launch_bounds__(KM_T) void k_kmeans_fit(const u8* __restrict__ data
 struct KmGlobal {
     unsigned bar_count, bar_gen;
     long long acc[8];                              // rotating accumulators of the integer passes
+    long long acc3[8][4];                          // the same for passes that sum three values at once (the three trials of a ++ centre)
+    int ci3[4];                                    // the three trial centres of a ++ step
     long long tot[2][ORIP_MAX_LAYERS * 4];         // cluster sums (L, a, b, count), double-buffered by iteration parity
     unsigned long long key;                        // farthest-point search of the empty-cluster repair
     int ci;
@@ -439,17 +441,29 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
     const int lo = min(N, gtid * chunk), hi = min(N, lo + chunk);
     unsigned long long rng = 0xffffffffULL;   // identical in every thread
     double best_compact = 1.79769313486231570815e+308;
-    int32_t *dist = dist0, *tdist = dist1, *tdist2 = dist2;
+    int32_t* dist = dist0; (void)dist1; (void)dist2;      // (the trials of a ++ centre no longer write candidate distance arrays)
     unsigned pass = 0;                        // selects the accumulator; slot pass+4 is cleared for later use
     // grid-wide integer sum of v (one value per thread); two barriers apart accumulators never collide
     auto grid_sum = [&](long long v) -> long long {
         long long bs = kmb_block_sum(v, red);
         const unsigned slot = pass & 7u;
-        if (tid == 0) { atomicAdd((unsigned long long*)&G->acc[slot], (unsigned long long)bs); if (bid == 0) G->acc[(pass + 4u) & 7u] = 0; }
+        if (tid == 0) { atomicAdd((unsigned long long*)&G->acc[slot], (unsigned long long)bs); if (bid == 0) { const unsigned z = (pass + 4u) & 7u; G->acc[z] = 0; G->acc3[z][0] = G->acc3[z][1] = G->acc3[z][2] = 0; } }
         km_grid_sync(G);
         long long r = *(volatile long long*)&G->acc[slot];
         pass++;
         return r;
+    };
+    auto grid_sum3 = [&](long long v0, long long v1, long long v2, long long (&r)[3]) {
+        const long long b0 = kmb_block_sum(v0, red), b1 = kmb_block_sum(v1, red), b2 = kmb_block_sum(v2, red);
+        const unsigned slot = pass & 7u;
+        if (tid == 0) {
+            atomicAdd((unsigned long long*)&G->acc3[slot][0], (unsigned long long)b0); atomicAdd((unsigned long long*)&G->acc3[slot][1], (unsigned long long)b1);
+            atomicAdd((unsigned long long*)&G->acc3[slot][2], (unsigned long long)b2);
+            if (bid == 0) { const unsigned z = (pass + 4u) & 7u; G->acc[z] = 0; G->acc3[z][0] = G->acc3[z][1] = G->acc3[z][2] = 0; }
+        }
+        km_grid_sync(G);
+        for (int j = 0; j < 3; j++) r[j] = *(volatile long long*)&G->acc3[slot][j];
+        pass++;
     };
     for (int a = 0; a < attempts; a++) {
         double compactness = 0;
@@ -466,20 +480,25 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
                 long long ls = 0;
                 for (int i = gtid; i < N; i += gsz) { int d = isq3(data + 3 * i, data + 3 * c0); dist[i] = d; ls += d; }
                 long long sum0 = grid_sum(ls);
+                // The three trials of a centre (02:47 -> cv::generateCentersPP, 3 trials per centre) share the distances they start from, so they run
+                // side by side: ONE pass of partial sums, the three descents in one phase, the three candidate sums in one reduction -- 3 grid
+                // barriers per centre instead of 9 (the fit is barrier-bound: 200 000 samples on 16 384 threads).  Every thread keeps its own
+                // contiguous chunk [lo, hi) from the update of the distances through the partial sums to the candidate sums, so no barrier is
+                // needed between a centre's update and the next centre's sums.  Same draws in the same order, same integer arithmetic.
                 for (int k = 1; k < K; k++) {
-                    long long bestSum = 0x7fffffffffffffffLL; int bestCenter = -1;
-                    for (int j = 0; j < 3; j++) {
-                        double p = km_double(rng) * (double)sum0;
-                        // ci = first index with inclusive prefix >= p, else N-1: contiguous chunk per thread, block totals, then one thread descends
-                        long long cs = 0;
-                        for (int i = lo; i < hi; i++) cs += dist[i];
-                        parts[gtid] = cs;
-                        long long bs = kmb_block_sum(cs, red);
-                        if (tid == 0) G->blockpart[bid] = bs;
-                        km_grid_sync(G);
-                        if (bid == 0 && tid < 64) {
-                            // first wave of block 0 descends: block totals, the threads of the crossing block, then the samples of the crossing
-                            // chunk; every test is "(double)(inclusive integer prefix) >= p" on exact integers, as in the scalar descent
+                    double pj[3];
+                    for (int j = 0; j < 3; j++) pj[j] = km_double(rng) * (double)sum0;
+                    long long cs = 0;
+                    for (int i = lo; i < hi; i++) cs += dist[i];
+                    parts[gtid] = cs;
+                    long long bs = kmb_block_sum(cs, red);
+                    if (tid == 0) G->blockpart[bid] = bs;
+                    km_grid_sync(G);
+                    if (bid == 0 && tid < 64) {
+                        for (int j = 0; j < 3; j++) {
+                            const double p = pj[j];
+                            // ci = first index with inclusive prefix >= p, else N-1.  First wave of block 0 descends: block totals, the threads of the crossing
+                            // block, then the samples of the crossing chunk; every test is "(double)(inclusive integer prefix) >= p" on exact integers
                             auto wave_incl = [&](long long v) { for (int o = 1; o < 64; o <<= 1) { long long t = __shfl_up(v, o, 64); if (tid >= o) v += t; } return v; };
                             auto first_cross = [&](long long base, long long v, bool valid, long long& before) -> int {   // lane index of the first crossing, -1: none
                                 const long long inc = wave_incl(valid ? v : 0);
@@ -514,18 +533,22 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
                                 }
                             }
                             if (ci > N - 1) ci = N - 1;
-                            if (tid == 0) G->ci = ci;
+                            if (tid == 0) G->ci3[j] = ci;
                         }
-                        km_grid_sync(G);
-                        const int ci = *(volatile int*)&G->ci;
-                        long long s = 0;
-                        for (int i = gtid; i < N; i += gsz) { int d = min(isq3(data + 3 * i, data + 3 * ci), dist[i]); tdist2[i] = d; s += d; }
-                        long long S = grid_sum(s);
-                        if (S < bestSum) { bestSum = S; bestCenter = ci; int32_t* t = tdist; tdist = tdist2; tdist2 = t; }
                     }
+                    km_grid_sync(G);
+                    int cj[3]; for (int j = 0; j < 3; j++) cj[j] = *(volatile int*)&G->ci3[j];
+                    long long sj[3] = {0, 0, 0};
+                    for (int i = lo; i < hi; i++) {
+                        const int d0 = dist[i];
+                        for (int j = 0; j < 3; j++) sj[j] += min(isq3(data + 3 * i, data + 3 * cj[j]), d0);
+                    }
+                    long long Sj[3]; grid_sum3(sj[0], sj[1], sj[2], Sj);
+                    long long bestSum = 0x7fffffffffffffffLL; int bestCenter = -1;
+                    for (int j = 0; j < 3; j++) if (Sj[j] < bestSum) { bestSum = Sj[j]; bestCenter = cj[j]; }
                     if (tid == 0) pp_idx[k] = bestCenter;
                     sum0 = bestSum;
-                    { int32_t* t = dist; dist = tdist; tdist = t; }
+                    if (k + 1 < K) for (int i = lo; i < hi; i++) dist[i] = min(isq3(data + 3 * i, data + 3 * bestCenter), dist[i]);      // own chunk: read next by this thread only, then (after a barrier) by the descent
                     __syncthreads();
                 }
                 __syncthreads();
