@@ -424,10 +424,13 @@ __device__ __forceinline__ long long kmb_block_sum(long long v, long long* red) 
     for (int w = 0; w < KMB_T / 64; w++) r += red[w];
     return r;
 }
-__global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ data, int N, int K, int attempts, int maxCount, double epsilon,
-                                                          int32_t* __restrict__ dist0, int32_t* __restrict__ dist1, int32_t* __restrict__ dist2, int32_t* __restrict__ labels,
-                                                          double* __restrict__ dd, long long* __restrict__ parts, float* __restrict__ centers_out,
-                                                          double* __restrict__ compact_out, int* __restrict__ status, KmGlobal* __restrict__ G) {
+// Attempts are independent but for the random draws, and every attempt makes the same number of them (one index, 3 (K - 1) doubles): `groups` groups of KMB_B
+// workgroups take the attempts a = group, group + groups, ... side by side (the fit is bound by its grid barriers, not by the card), each with its own
+// barrier, accumulators and work arrays; the host takes the first attempt with the smallest compactness, as the sequential loop does (02:46-49).
+struct KmResult { float cen[ORIP_MAX_LAYERS * 3]; double compact; int attempt; int status; int pad[2]; };
+__global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ data, int N, int K, int attempts, int groups, int maxCount, double epsilon,
+                                                          int32_t* __restrict__ dist_all, int32_t* __restrict__ labels_all,
+                                                          double* __restrict__ dd_all, long long* __restrict__ parts_all, KmResult* __restrict__ res_all, KmGlobal* __restrict__ G_all) {
     __shared__ long long red[KMB_T / 64];
     __shared__ float centers[ORIP_MAX_LAYERS * 3], old_centers[ORIP_MAX_LAYERS * 3];
     __shared__ int csum[KMB_T / 64][ORIP_MAX_LAYERS * 4];
@@ -435,13 +438,15 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
     __shared__ int pp_idx[ORIP_MAX_LAYERS];
     __shared__ double sh_shift;
     __shared__ double ptree[1024];
-    const int tid = threadIdx.x, wave = tid >> 6, bid = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, grp = blockIdx.x / KMB_B, bid = blockIdx.x % KMB_B;
     const int gtid = bid * KMB_T + tid, gsz = KMB_B * KMB_T;
     const int chunk = (N + gsz - 1) / gsz;
     const int lo = min(N, gtid * chunk), hi = min(N, lo + chunk);
     unsigned long long rng = 0xffffffffULL;   // identical in every thread
-    double best_compact = 1.79769313486231570815e+308;
-    int32_t* dist = dist0; (void)dist1; (void)dist2;      // (the trials of a ++ centre no longer write candidate distance arrays)
+    double best_compact = 1.79769313486231570815e+308; int best_attempt = -1;
+    int32_t* dist = dist_all + (size_t)grp * N; int32_t* labels = labels_all + (size_t)grp * N;      // (the trials of a ++ centre no longer write candidate distance arrays)
+    double* dd = dd_all + (size_t)grp * N; long long* parts = parts_all + (size_t)grp * KMB_B * KMB_T;
+    KmGlobal* G = G_all + grp; KmResult* res = res_all + grp;
     unsigned pass = 0;                        // selects the accumulator; slot pass+4 is cleared for later use
     // grid-wide integer sum of v (one value per thread); two barriers apart accumulators never collide
     auto grid_sum = [&](long long v) -> long long {
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
         pass++;
     };
     for (int a = 0; a < attempts; a++) {
+        if (a % groups != grp) { for (int q = 0; q < 1 + 6 * (K - 1); q++) km_next(rng); continue; }      // another group's attempt: its draws
         double compactness = 0;
         for (int iter = 0;;) {
             double max_shift = iter == 0 ? 1.79769313486231570815e+308 : 0.0;
@@ -667,12 +673,12 @@ __global__ __launch_bounds__(KMB_T) void k_kmeans_fit_mb(const u8* __restrict__ 
             }
         }
         if (compactness < best_compact) {
-            best_compact = compactness;
-            if (bid == 0 && tid < K * 3) centers_out[tid] = centers[tid];
+            best_compact = compactness; best_attempt = a;
+            if (bid == 0 && tid < K * 3) res->cen[tid] = centers[tid];
         }
         __syncthreads();
     }
-    if (bid == 0 && tid == 0) { *compact_out = best_compact; *status = 0; }
+    if (bid == 0 && tid == 0) { res->compact = best_compact; res->attempt = best_attempt; res->status = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -917,12 +923,32 @@ static int kmeans_fit_impl(orip_ctx* c, bool rgb, const int64_t* sample_idx, int
         hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
                            base, base + N, base + 2 * N, base + 3 * N, d_centers, d_comp, d_status);
     } else {
-        HIPC(c, c->tmpA.ensure((size_t)N * 8 + (size_t)KMB_B * KMB_T * 8 + sizeof(KmGlobal) + 256));
-        double* dd = c->tmpA.as<double>(); long long* parts = (long long*)(dd + N); KmGlobal* G = (KmGlobal*)(parts + KMB_B * KMB_T);
-        HIPC(c, hipMemsetAsync(G, 0, sizeof(KmGlobal), LN(c).stream));
-        ProfScope ps(c, "k_kmeans_fit");
-        hipLaunchKernelGGL(k_kmeans_fit_mb, dim3(KMB_B), dim3(KMB_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
-                           base, base + N, base + 2 * N, base + 3 * N, dd, parts, d_centers, d_comp, d_status, G);
+        const int groups = std::min(attempts, 4);
+        HIPC(c, c->tmpD.ensure((size_t)N * 4 * 2 * groups + 256));
+        base = c->tmpD.as<int32_t>();
+        const size_t per = (size_t)N * 8 + (size_t)KMB_B * KMB_T * 8;
+        HIPC(c, c->tmpA.ensure(per * groups + (sizeof(KmGlobal) + sizeof(KmResult)) * groups + 256));
+        double* dd = c->tmpA.as<double>(); long long* parts = (long long*)(dd + (size_t)N * groups);
+        KmGlobal* G = (KmGlobal*)(parts + (size_t)KMB_B * KMB_T * groups); KmResult* res = (KmResult*)(G + groups);
+        HIPC(c, hipMemsetAsync(G, 0, sizeof(KmGlobal) * groups, LN(c).stream));
+        HIPC(c, hipMemsetAsync(res, 0xff, sizeof(KmResult) * groups, LN(c).stream));
+        {
+            ProfScope ps(c, "k_kmeans_fit");
+            hipLaunchKernelGGL(k_kmeans_fit_mb, dim3(KMB_B * groups), dim3(KMB_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, groups, maxCount, epsilon,
+                               base, base + (size_t)N * groups, dd, parts, res, G);
+        }
+        HIPC(c, hipGetLastError());
+        KmResult hr[4];
+        HIPC(c, hipMemcpyAsync(hr, res, sizeof(KmResult) * groups, hipMemcpyDeviceToHost, LN(c).stream));
+        HIPC(c, hipStreamSynchronize(LN(c).stream));
+        int bg = -1;
+        for (int g = 0; g < groups; g++) {
+            if (hr[g].status != 0) ORIP_FAIL(c, "kmeans kernel did not complete (group %d, status %d)", g, hr[g].status);
+            if (bg < 0 || hr[g].compact < hr[bg].compact || (hr[g].compact == hr[bg].compact && hr[g].attempt < hr[bg].attempt)) bg = g;
+        }
+        memcpy(centers_out, hr[bg].cen, sizeof(float) * K * 3);
+        if (compactness_out) *compactness_out = hr[bg].compact;
+        return 0;
     }
     HIPC(c, hipGetLastError());
     struct { float cen[ORIP_MAX_LAYERS * 3]; } hc; double comp; int st;
