@@ -396,6 +396,53 @@ __global__ __launch_bounds__(256) void k_poly_features_long(Src src, int64_t n_p
     }
 }
 // features of every polyline of a list: short ones one lane each, long ones one block each
+// cv::arcLength(contour, closed = true) (07:50) of the long contours of a walk-coded list whose polylines are whole walks, WITHOUT visiting their points:
+// a walk is its own points plus tail pieces that run through consecutive log entries, the last ones lap after lap around one cycle (walker.h: VWalk /
+// VPiece), so its perimeter is the own segments + per piece the segments of one lap (x laps) and of the partial lap + the junctions.  The reference adds the
+// float32 segment lengths into a double; every length is a multiple of 2^-23 and the total stays below 2^22, so every partial sum is exact and the order (and
+// the multiplication by the lap count) cannot change the result -- the same argument k_poly_features_long's parallel sum rests on.  One wave per walk; the pass
+// over 2.8e8 points it replaces sat on the chain in front of stage 07's greedy order with 1 - 4 ms.
+__global__ __launch_bounds__(64) void k_walk_arcs(VSrc src, int64_t n_polys, PolyFeat* __restrict__ feat) {
+    const int lane = threadIdx.x;
+    auto len2 = [](const int2 a, const int2 b) -> double {
+        const float dx = (float)a.x - (float)b.x, dy = (float)a.y - (float)b.y;
+        return (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    };
+    auto wave_sum = [](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    for (int64_t i = blockIdx.x; i < n_polys; i += gridDim.x) {
+        if (feat[i].n <= ORIP_LONG_POLY) continue;           // the short ones have their sum from k_poly_features
+        const VWalk w = src.walk[i];
+        const int2* own = src.g.own + w.own_off;
+        double acc = 0.0;
+        for (unsigned t = 1u + (unsigned)lane; t <= w.n_own; t += 64u) acc += len2(own[t], own[t - 1u]);
+        const unsigned closing = w.flags & 1u;
+        const unsigned T = w.len - closing - (w.n_own + 1u);      // tail points
+        int2 last = own[w.n_own];
+        for (unsigned j = 0; j < w.n_piece && T > 0u; j++) {
+            const VPiece q = src.g.piece[w.piece_off + j];
+            const unsigned cnt = (j + 1u < w.n_piece ? src.g.piece[w.piece_off + j + 1u].u0 : T) - q.u0;
+            if (cnt == 0u) continue;
+            const int2* L = src.g.lxy + q.ent;
+            if (lane == 0) acc += len2(L[0], last);               // the junction into the piece
+            if (q.lam == 0u) {
+                for (unsigned e = (unsigned)lane; e + 1u < cnt; e += 64u) acc += len2(L[e + 1u], L[e]);
+                last = L[cnt - 1u];
+            } else {
+                // points m = 0 .. cnt - 1 sit at entry m mod lam: step m wraps iff m mod lam == 0, every lap is the lam - 1 inner steps + the wrap
+                const unsigned laps = (cnt - 1u) / q.lam, r = (cnt - 1u) % q.lam;
+                double full = 0.0, part = 0.0;
+                for (unsigned e = (unsigned)lane; e + 1u < q.lam; e += 64u) { const double d = len2(L[e + 1u], L[e]); full += d; if (e < r) part += d; }
+                full = wave_sum(full);
+                if (lane == 0) acc += (double)laps * (full + len2(L[0], L[q.lam - 1u]));
+                acc += part;
+                last = L[r];
+            }
+        }
+        if (lane == 0) acc += len2(own[0], last);                 // to the closing point when there is one (then the wrap is 0), else the closed contour's wrap
+        acc = wave_sum(acc);
+        if (lane == 0) feat[i].arc = acc;
+    }
+}
 // the long polylines' part of vfeatures_src; seg != nullptr: their perimeters from stored segment lengths (what == 1 | 16 [| 32]; bounding boxes already in feat)
 template <class Src>
 static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev, const float* seg = nullptr) {
@@ -1359,7 +1406,12 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     int32_t* order = (int32_t*)(desc + n);
     uint8_t* flips = (uint8_t*)(order + n); uint8_t* used = flips + n;
     int what = kind == 7 ? 4 : (kind == 8 ? 1 : 8);
-    ORIP_TRY(vfeatures(c, src, what, feat));
+    if (kind == 7 && is_coded(src) && src.vident && !getenv("ORIP_ARC_POINTS")) {      // whole walks: the long contours' arc lengths from the walk records
+        VSrc vs_; ORIP_TRY(vsrc_of(c, src, vs_));
+        hipLaunchKernelGGL(k_poly_features<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, vs_, n, what, feat, (float*)nullptr);
+        if (src.total > ORIP_LONG_POLY) { ProfScope ps(c, "k_walk_arcs"); hipLaunchKernelGGL(k_walk_arcs, dim3((unsigned)std::min<int64_t>(n, 16384)), dim3(64), 0, LN(c).stream, vs_, n, feat); }
+        HIPC(c, hipGetLastError());
+    } else ORIP_TRY(vfeatures(c, src, what, feat));
     ORIP_WITH_SRC(c, src, ps, { hipLaunchKernelGGL(k_ends_from_feat<decltype(ps)>, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, ps, ends); });
     int* d_seed = LN(c).flags.as<int>() + 32;
     HIPC(c, hipMemsetAsync(d_seed + 1, 0, 4, LN(c).stream));
