@@ -2,7 +2,7 @@
 (development aid: a gap is a host round trip, a wait for another queue, or host work).  usage: python tools/chain_gaps.py <dir-or-csv> [MIN_MS]"""
 import csv, glob, os, re, sys
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.08
-files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True)
+files = [p] if p.endswith(".csv") else sorted(glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]      # a directory that collected several runs (gpurun merges them): the newest one, never a mix
 rows = []
 for f in files:
     with open(f) as fh:

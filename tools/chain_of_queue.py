@@ -3,7 +3,7 @@ with the idle gap before each and a per-kernel total (development aid).  usage: 
 import csv, glob, os, re, sys
 from collections import defaultdict
 p = sys.argv[1]; min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
-files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True)
+files = [p] if p.endswith(".csv") else sorted(glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]      # a directory that collected several runs (gpurun merges them): the newest one, never a mix
 rows = []
 for f in files:
     with open(f) as fh:

@@ -3,7 +3,7 @@ usage: python tools/trace_top.py <dir-or-csv> [N]"""
 import csv, glob, os, sys
 from collections import defaultdict
 p = sys.argv[1]; N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-files = [p] if p.endswith(".csv") else glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True)
+files = [p] if p.endswith(".csv") else sorted(glob.glob(os.path.join(p, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]      # a directory that collected several runs (gpurun merges them): the newest one, never a mix
 rows = []
 for f in files:
     with open(f) as fh:
