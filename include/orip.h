@@ -150,6 +150,12 @@ int orip_dedup_cross_layer_from(orip_ctx* ctx, int src_layer, int layer);
 /* same, but the travel reorder of the kept lines (10:253) is left to orip_plot_order(layer), which runs it first on the layer's own
  * stream: LINES_CROSS of `layer` is in cut order until then (resident pipelines only; nothing else in stage 10 depends on that order) */
 int orip_dedup_cross_layer_deferred(orip_ctx* ctx, int src_layer, int layer);
+/* ---- previews 06 / 09 / 11 (06_preview_scaled.py:76-88 _draw_layer, 09_preview_intra.py:71-88 _draw_lines / _draw_taps, 11_preview_cross.py) ----
+ * Coverage planes (0 = untouched .. 255 = fully covered, H*W bytes each, host buffers, either may be NULL) of the polylines of (slot, layer) drawn
+ * `thickness` px wide and of the taps `taps_which` (ORIP_TAPS_INTRA / ORIP_TAPS_CROSS, -1: none) as filled discs of `radius` px.  antialias != 0: the
+ * coverage falls off linearly over one pixel around the outline.  This stands in for cv2.LINE_AA, which the reference's tests do not pin: PARITY
+ * UNPINNED, visual QA only (csrc/vector_preview.hip states what is drawn; oracle/oracle.py: preview_cover is the same, bit for bit). */
+int orip_preview_cover(orip_ctx* ctx, int slot, int layer, int taps_which, int W, int H, int thickness, int radius, int antialias, uint8_t* line_cov, uint8_t* tap_cov);
 /* ---- stage 12: _build_ops_for_layer (12:85-187): LINES/TAPS_CROSS -> ops ----
  * ops are returned as 5 int32 each: (type 0 line / 1 tap, line index into LINES_CROSS, flip, x, y). */
 int orip_plot_order(orip_ctx* ctx, int layer, double R_insert, int64_t* n_ops);

@@ -290,6 +290,12 @@ class Device:
     def bcast_layer(self, root: int, my_slot: int):
         self._ck(self.L.orip_bcast_layer(self.h, int(root), int(my_slot)))
 
+    def preview_cover(self, slot: int, layer: int, taps_which: int, W: int, H: int, thickness: int, radius: int, antialias: bool):
+        """Coverage planes (lines, taps), uint8 (H, W) each, behind the previews 06 / 09 / 11 (include/orip.h: orip_preview_cover; parity unpinned)."""
+        lines = np.zeros((H, W), np.uint8); taps = np.zeros((H, W), np.uint8)
+        self._ck(self.L.orip_preview_cover(self.h, int(slot), int(layer), int(taps_which), int(W), int(H), int(thickness), int(radius), 1 if antialias else 0, _p(lines), _p(taps)))
+        return lines, taps
+
     def plot_order(self, layer: int, R_insert: float) -> np.ndarray:
         n = C.c_int64(0)
         self._ck(self.L.orip_plot_order(self.h, layer, float(R_insert), C.byref(n)))

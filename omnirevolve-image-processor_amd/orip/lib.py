@@ -57,6 +57,7 @@ SIGNATURES = {
     "orip_scale_vectors": (_i32, [_vp, _i32, _f32, _f32, _f32, _f32]), "orip_sort_contours": (_i32, [_vp, _i32]),
     "orip_dedup_layer": (_i32, [_vp, _i32, _P(Params08)]), "orip_layer_front": (_i32, [_vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]), "orip_dedup_cross": (_i32, [_vp, _vp, _i32, _P(Params10)]),
     "orip_plot_order": (_i32, [_vp, _i32, _f64, _P(_i64)]), "orip_get_ops": (_i32, [_vp, _i32, _vp]),
+    "orip_preview_cover": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "orip_stream_codes": (_i32, [_vp, _vp, _i64, _P(_i64)]), "orip_stream_codes_fetch": (_i32, [_vp, _vp, _vp]),
     "orip_comm_unique_id": (_i32, [_vp]), "orip_comm_init": (_i32, [_vp, _vp, _i32, _i32]), "orip_comm_destroy": (_i32, [_vp]),
     "orip_bcast_layer": (_i32, [_vp, _i32, _i32]),

@@ -202,6 +202,55 @@ def dedup_cross(intra: Dict[str, Tuple[Sequence[np.ndarray], Sequence[Tuple[int,
     return {n: (d.get_polys(_l.SLOT_LINES_CROSS, l), d.get_taps(_l.TAPS_CROSS, l)) for l, n in enumerate(names)}
 
 
+# ---- previews 06 / 09 / 11 (visual QA; parity unpinned: include/orip.h orip_preview_cover says what is drawn instead of cv2.LINE_AA) ----
+def preview_cover(polys: Sequence[np.ndarray], taps: Sequence[Tuple[int, int]], size: Tuple[int, int], thickness: int, radius: int, antialias: bool,
+                  dev: Device | None = None, layer: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Coverage planes (lines, taps), uint8 (H, W), of one layer's polylines and taps on the full canvas `size` = (W, H)."""
+    d = dev or device()
+    d.set_polys(_l.SLOT_LINES_CROSS, layer, polys)
+    d.set_taps(_l.TAPS_CROSS, layer, taps)
+    return d.preview_cover(_l.SLOT_LINES_CROSS, layer, _l.TAPS_CROSS, size[0], size[1], max(1, int(thickness)), max(0, int(radius)), bool(antialias))
+
+
+def preview_compose(img: np.ndarray, cover: np.ndarray, bgr) -> np.ndarray:
+    """`bgr` laid over img (H, W, 3) uint8 at coverage `cover` (H, W) uint8: (img (255 - A) + colour A + 127) // 255 per channel."""
+    A = cover.astype(np.int32)[:, :, None]
+    col = np.asarray(bgr, np.int32).reshape(1, 1, 3)
+    return ((img.astype(np.int32) * (255 - A) + col * A + 127) // 255).astype(np.uint8)
+
+
+def preview_images(polys, taps, size, thickness: int, radius: int, antialias: bool, color, tap_color_layer=(0, 0, 255), dev: Device | None = None):
+    """One layer of a preview stage: (layer image, colour image) as 09:103-118 builds them -- black lines and `tap_color_layer` discs on white for
+    <layer>/preview_*.png, lines and discs in the layer's colour for the composite (06 has no taps: pass [])."""
+    cov_l, cov_t = preview_cover(polys, taps, size, thickness, radius, antialias, dev)
+    white = np.full((size[1], size[0], 3), 255, np.uint8)
+    lay = preview_compose(preview_compose(white, cov_l, (0, 0, 0)), cov_t, tap_color_layer)
+    col = preview_compose(preview_compose(white, cov_l, color), cov_t, color)
+    return lay, col
+
+
+def preview_palette(cfg: Config) -> Dict[str, Tuple[int, int, int]]:
+    """_load_palette_by_name (06:46-62) / _palette (09:27-42): approx_bgr of palette_by_name.json, else cfg.colors[i]."""
+    import json
+    import os
+    data = None
+    path = os.path.join(cfg.output_dir, "palette_by_name.json")
+    if os.path.exists(path):
+        try:
+            with open(path, "r", encoding="utf-8") as f:
+                data = json.load(f)
+        except Exception:
+            data = None
+    out = {}
+    for i, n in enumerate(cfg.color_names):
+        if data and n in data and "approx_bgr" in data[n]:
+            b, g, r = data[n]["approx_bgr"]
+        else:
+            b, g, r = cfg.colors[i]
+        out[n] = (int(b), int(g), int(r))
+    return out
+
+
 def ops_from_device(d: Device, layer: int, R: float) -> List[dict]:
     raw = d.plot_order(layer, R)
     lines = d.get_polys(_l.SLOT_LINES_CROSS, layer) if len(raw) else []

@@ -1,7 +1,6 @@
 # pipeline.py -- runner with the reference's contract (pipeline.py:66-224) for the stages this repository provides:
-# one subprocess per stage, CONFIG_PATH in the environment, stdout streamed, non-zero exit aborts.  Stages outside the
-# hot path (01 resize, previews 06/09/11, 13/14 stream) are not part of this repository: pass --ref-dir to run the
-# reference's own scripts for them, otherwise they are skipped with a notice.
+# one subprocess per stage, CONFIG_PATH in the environment, stdout streamed, non-zero exit aborts.  A stage this repository
+# does not provide (14 stream preview) is run from --ref-dir (the reference's own script) when given, otherwise skipped with a notice.
 import argparse
 import json
 import os

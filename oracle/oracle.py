@@ -430,6 +430,55 @@ def build_ops12(lines, taps, R_insert=80.0) -> List[dict]:
 
 
 # ------------------------------------------------------------------ stage-level composition
+def preview_cover(polys, taps, W: int, H: int, thickness: int = 1, radius: int = 30, antialias: bool = True):
+    """Coverage planes behind the previews 06 / 09 / 11 (06:76-88 _draw_layer, 09:71-88 _draw_lines / _draw_taps): (lines, taps), uint8 H x W,
+    0 = untouched .. 255 = fully covered.  PARITY UNPINNED against cv2.polylines / cv2.circle with LINE_AA (the reference's tests hold nothing for
+    them and cv2 is not importable here): what is drawn is the documented stand-in of csrc/vector_preview.hip -- coverage of a pixel centre by a
+    segment clamp(thickness / 2 + 0.5 - d, 0, 1) with d the Euclidean distance to the segment (anti-aliasing off: d <= thickness / 2), by a tap
+    clamp(radius + 0.5 - d, 0, 1); per pixel the largest coverage, stored as floor(255 a + 0.5).  float64 throughout, same order of operations as the
+    kernel (this function is what the GPU tests compare with, bit for bit)."""
+    lines = np.zeros((H, W), np.int32); discs = np.zeros((H, W), np.int32)
+    half = np.float64(thickness) * 0.5
+    def cov(a):
+        return np.floor(np.clip(a, 0.0, 1.0) * 255.0 + 0.5).astype(np.int32)
+    for poly in polys:
+        p = np.asarray(poly).reshape(-1, 2).astype(np.int64)
+        r = int(np.ceil(half + 0.5))
+        for k in range(len(p) - 1):
+            x0, y0 = int(p[k, 0]), int(p[k, 1]); x1, y1 = int(p[k + 1, 0]), int(p[k + 1, 1])
+            xa, xb = max(0, min(x0, x1) - r), min(W - 1, max(x0, x1) + r); ya, yb = max(0, min(y0, y1) - r), min(H - 1, max(y0, y1) + r)
+            if xa > xb or ya > yb:
+                continue
+            ys, xs = np.mgrid[ya:yb + 1, xa:xb + 1]
+            vx, vy = np.float64(x1 - x0), np.float64(y1 - y0)
+            wx, wy = xs.astype(np.float64) - np.float64(x0), ys.astype(np.float64) - np.float64(y0)
+            L2 = vx * vx + vy * vy
+            t = np.clip((wx * vx + wy * vy) / L2, 0.0, 1.0) if L2 > 0 else np.zeros_like(wx)
+            dx, dy = wx - t * vx, wy - t * vy
+            d = np.sqrt(dx * dx + dy * dy)
+            A = cov((half + 0.5) - d) if antialias else np.where(d <= half, 255, 0).astype(np.int32)
+            np.maximum(lines[ya:yb + 1, xa:xb + 1], A, out=lines[ya:yb + 1, xa:xb + 1])
+    rad = np.float64(radius); r = int(np.ceil(rad + 0.5))
+    for (cx, cy) in taps:
+        cx, cy = int(cx), int(cy)
+        xa, xb = max(0, cx - r), min(W - 1, cx + r); ya, yb = max(0, cy - r), min(H - 1, cy + r)
+        if xa > xb or ya > yb:
+            continue
+        ys, xs = np.mgrid[ya:yb + 1, xa:xb + 1]
+        dx, dy = xs.astype(np.float64) - np.float64(cx), ys.astype(np.float64) - np.float64(cy)
+        d = np.sqrt(dx * dx + dy * dy)
+        A = cov((rad + 0.5) - d) if antialias else np.where(d <= rad, 255, 0).astype(np.int32)
+        np.maximum(discs[ya:yb + 1, xa:xb + 1], A, out=discs[ya:yb + 1, xa:xb + 1])
+    return lines.astype(np.uint8), discs.astype(np.uint8)
+
+
+def preview_compose(img: np.ndarray, cover: np.ndarray, bgr) -> np.ndarray:
+    """img (H, W, 3) uint8 with `bgr` laid over it at coverage `cover` (H, W) uint8: (img (255 - A) + colour A + 127) // 255 per channel."""
+    A = cover.astype(np.int32)[:, :, None]
+    col = np.asarray(bgr, np.int32).reshape(1, 1, 3)
+    return ((img.astype(np.int32) * (255 - A) + col * A + 127) // 255).astype(np.uint8)
+
+
 DEFAULTS = dict(
     color_names=["layer_dark", "layer_mid", "layer_skin", "layer_light"],
     edge_low_threshold=50, edge_high_threshold=150, edge_kernel_size=3, edge_morph_kernel=3,
