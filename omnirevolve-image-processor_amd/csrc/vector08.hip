@@ -1791,17 +1791,21 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             const dim3 gwd((unsigned)cdiv((int64_t)nwords, 256));
             hipLaunchKernelGGL(k_gid_to_bits, gwd, blk, 0, LN(c).stream, gid, bA, Hp, Wp, Wwp);      // 4 waves x 64 words per block
             tick("raster");
-            // four iterations per round trip to the host, each with its own flag: an iteration after the first unchanged one changes nothing
-            // either, so running to the end of the batch leaves the image the reference's loop stops with (48 = 12 batches: same cap)
-            int* d_ch4 = LN(c).flags.as<int>() + 208;
-            for (int it = 0; it < 48; it += 4) {
-                HIPC(c, hipMemsetAsync(d_ch4, 0, 16, LN(c).stream));
-                for (int b = 0; b < 4; b++) {
-                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_ch4 + b); }
-                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_ch4 + b); }
+            // Twelve iterations before the first round trip to the host (16-px lines thin in 9 .. 12), four per round trip after that, each iteration with
+            // its own flag: an iteration after the first unchanged one changes nothing either, so running to the end of a batch leaves the image the
+            // reference's loop stops with (48 iterations at most: the same cap)
+            int* d_chg = LN(c).flags.as<int>() + 240;
+            for (int it = 0; it < 48; ) {
+                const int nb = it == 0 ? 12 : 4;
+                HIPC(c, hipMemsetAsync(d_chg, 0, 48, LN(c).stream));
+                for (int b = 0; b < nb; b++) {
+                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_chg + b); }
+                    { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_chg + b); }
                 }
-                int ch[4] = {0, 0, 0, 0}; ORIP_TRY(vread(c, ch, d_ch4, 4));
-                if (!(ch[0] && ch[1] && ch[2] && ch[3])) break;
+                int ch[12] = {0}; ORIP_TRY(vread(c, ch, d_chg, 12));
+                bool all = true; for (int b = 0; b < nb; b++) all = all && ch[b] != 0;
+                if (!all) break;
+                it += nb;
             }
             hipLaunchKernelGGL(k_bits_to_mask, gwd, blk, 0, LN(c).stream, bA, skA, Hp, Wp, Wwp);
         } else {
