@@ -150,6 +150,10 @@ int orip_dedup_cross_layer_from(orip_ctx* ctx, int src_layer, int layer);
 /* same, but the travel reorder of the kept lines (10:253) is left to orip_plot_order(layer), which runs it first on the layer's own
  * stream: LINES_CROSS of `layer` is in cut order until then (resident pipelines only; nothing else in stage 10 depends on that order) */
 int orip_dedup_cross_layer_deferred(orip_ctx* ctx, int src_layer, int layer);
+/* 1 when the library was built with the replaced kernel variants (`make variants` -> liborip_variants.so, -DORIP_VARIANTS: the one-workgroup k-means
+ * fit, byte-plane thinning, the first grid greedy kernel, the sequential tail simulation, the serial cumulative-length chain; selected through
+ * their ORIP_* environment switches for agreement tests), 0 for the default library, where those switches read as not set. */
+int orip_has_variants(void);
 /* ---- previews 06 / 09 / 11 (06_preview_scaled.py:76-88 _draw_layer, 09_preview_intra.py:71-88 _draw_lines / _draw_taps, 11_preview_cross.py) ----
  * Coverage planes (0 = untouched .. 255 = fully covered, H*W bytes each, host buffers, either may be NULL) of the polylines of (slot, layer) drawn
  * `thickness` px wide and of the taps `taps_which` (ORIP_TAPS_INTRA / ORIP_TAPS_CROSS, -1: none) as filled discs of `radius` px.  antialias != 0: the

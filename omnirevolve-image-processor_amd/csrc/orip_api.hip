@@ -138,6 +138,13 @@ extern "C" int orip_taps_size(orip_ctx* c, int which, int layer, int64_t* n) {
     *n = c->taps[which][layer].n;
     return 0;
 }
+extern "C" int orip_has_variants(void) {
+#ifdef ORIP_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int orip_get_taps(orip_ctx* c, int which, int layer, int32_t* xy) {
     orip_enter(c);
     if (which < 0 || which > 1 || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad taps slot");

@@ -1,5 +1,16 @@
 // csrc/orip_ctx.h -- device context of liborip.so (gfx950 only).
 #pragma once
+// Kernel variants that newer ones have REPLACED and that nothing falls back to (the one-workgroup k-means fit, byte-plane thinning, the first grid greedy
+// kernel, the sequential tail simulation, the serial float chain of the cumulative lengths) are compiled into a variants build only (`make variants` ->
+// liborip_variants.so, -DORIP_VARIANTS): there their switches (ORIP_KMEANS_1WG, ORIP_THIN_BYTES, ORIP_NN_OLDGRID / ORIP_NN_DBG, ORIP_TAIL_OLDSIM,
+// ORIP_CUM_CHAIN) select them for the agreement tests; in the default library the switches read as not set.  (The other switches force paths the default
+// library needs anyway: byte morphology / CCL / NMS for inputs the bit-plane kernels do not take, the LDS-less greedy / plot-order kernels for large lists.)
+#ifdef ORIP_VARIANTS
+#define ORIP_VARIANT(name) (getenv(name) != nullptr)
+#else
+#define ORIP_VARIANT(name) false
+#endif
+
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -210,6 +210,7 @@ __device__ __forceinline__ float fsq3(const u8* a, const float* c) {
     return s;
 }
 
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_KMEANS_1WG): variants build only (make variants)
 __global__ __launch_bounds__(KM_T) void k_kmeans_fit(const u8* __restrict__ data, int N, int K, int attempts, int maxCount,
                                                       double epsilon, int32_t* __restrict__ dist0, int32_t* __restrict__ dist1,
                                                       int32_t* __restrict__ dist2, int32_t* __restrict__ labels,
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(KM_T) void k_kmeans_fit(const u8* __restrict__ data
     }
     if (tid == 0) { *compact_out = best_compact; *status = 0; }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // The same fit spread over KMB_B workgroups with a device-wide barrier between phases (the single workgroup above spends 13 ms
@@ -918,11 +920,14 @@ static int kmeans_fit_impl(orip_ctx* c, bool rgb, const int64_t* sample_idx, int
     double* d_comp = (double*)((char*)LN(c).flags.p + 512);
     int* d_status = (int*)LN(c).flags.p;
     HIPC(c, hipMemsetAsync(LN(c).flags.p, 0xff, 4, LN(c).stream));
-    if (getenv("ORIP_KMEANS_1WG")) {          // the single-workgroup version (test hook: both must give the same centres)
+#ifdef ORIP_VARIANTS
+    if (ORIP_VARIANT("ORIP_KMEANS_1WG")) {          // the single-workgroup version (test hook: both must give the same centres)
         ProfScope ps(c, "k_kmeans_fit");
         hipLaunchKernelGGL(k_kmeans_fit, dim3(1), dim3(KM_T), 0, LN(c).stream, c->tmpB.as<u8>(), (int)N, K, attempts, maxCount, epsilon,
                            base, base + N, base + 2 * N, base + 3 * N, d_centers, d_comp, d_status);
-    } else {
+    } else
+#endif
+    {
         const int groups = std::min(attempts, 4);
         HIPC(c, c->tmpD.ensure((size_t)N * 4 * 2 * groups + 256));
         base = c->tmpD.as<int32_t>();

@@ -19,6 +19,7 @@ int orip_ccl_bits(orip_ctx* c, const unsigned long long* bits, int* par, int K);
 // ------------------------------------------------------------------------------------------------
 // Thinning.  P2..P9 offsets (dy,dx) derived from the _shift() arguments at 04:53-55.
 // ------------------------------------------------------------------------------------------------
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_thin_sub(const u8* __restrict__ src, u8* __restrict__ dst, int H, int W, int sub, int* __restrict__ changed) {
     const size_t plane = (size_t)H * W;
     const u8* s = src + plane * blockIdx.z; u8* d = dst + plane * blockIdx.z;
@@ -36,10 +37,12 @@ __global__ __launch_bounds__(256) void k_thin_sub(const u8* __restrict__ src, u8
     }
     d[o] = v ? 255 : 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // state byte (walker.h): ST_FG, ST_VIS, ST_END (deg == 1), ST_JUN (deg >= 3)
 // ------------------------------------------------------------------------------------------------
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_skel_state(const u8* __restrict__ skel, u8* __restrict__ st, int H, int W) {
     const size_t plane = (size_t)H * W;
     const u8* s = skel + plane * blockIdx.z; u8* d = st + plane * blockIdx.z;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void k_skel_state(const u8* __restrict__ skel,
     }
     d[o] = v;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Ordered compaction (raster order inside a layer, layers in order): ballot + popcount inside the wave,
@@ -472,12 +476,12 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     HIPC(c, c->skel.ensure(plane * K + 16));
     HIPC(c, c->tmpB.ensure(plane * K + 16));
     HIPC(c, LN(c).flags.ensure(1024));
-    int* d_changed = LN(c).flags.as<int>() + 8;
+    int* d_changed = LN(c).flags.as<int>() + 8; (void)d_changed;
     dim3 g2(cdiv(W, 64), cdiv(H, 4), K), block(256);
     const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const size_t pplane = (size_t)Wb * Hb * 4;
     HIPC(c, c->tmpC.ensure(plane * K + 16));   // state bytes
     const unsigned long long* d2_plane = nullptr;   // degree-2 pixels as a bit plane (bit-plane thinning path only)
-    if (!getenv("ORIP_THIN_BYTES")) {
+    if (!ORIP_VARIANT("ORIP_THIN_BYTES")) {
         // bit planes: 2 MB per 4096^2 layer; pack, iterate, then skeleton and state bytes in one unpacking pass
         const int Ww = (W + 63) >> 6; const size_t nw = (size_t)H * Ww;
         HIPC(c, LN(c).vtmp[10].ensure(nw * K * 16 + 64));
@@ -500,7 +504,9 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         }
         { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_bits_to_skel_state, gw, block, 0, LN(c).stream, bA, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W, Ww, bB); }
         d2_plane = bB;                                   // (the second thinning plane is free now)
-    } else {
+    }
+#ifdef ORIP_VARIANTS
+    else {
         // iteration 1 reads the edges; ping-pong skel <-> tmpB so that the result always lands in skel
         const u8* cur = c->edges.as<u8>();
         for (int it = 0; it < 120; it++) {
@@ -515,6 +521,7 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
         }
         { ProfScope ps(c, "k_skel_state"); hipLaunchKernelGGL(k_skel_state, g2, block, 0, LN(c).stream, c->skel.as<u8>(), c->tmpC.as<u8>(), H, W); }
     }
+#endif
     // ---- forced stretches (walker.h: ST_CHAIN), on the side stream underneath the component work below; the traces wait for ev3.
     // Sized from the skeleton of the previous prepare of this context (a resident chain repeats itself), else from the pixel count: chains
     // that do not fit are simply not listed (k_chain_build), the walker then steps through them as before.
@@ -541,7 +548,7 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     }
     // ---- components (from the thinned bit planes when they exist)
     HIPC(c, c->tmpD.ensure(pplane * K * sizeof(int)));
-    if (!getenv("ORIP_THIN_BYTES") && !getenv("ORIP_CCL_BYTES")) ORIP_TRY(orip_ccl_bits(c, LN(c).vtmp[10].as<unsigned long long>(), c->tmpD.as<int>(), K));
+    if (!ORIP_VARIANT("ORIP_THIN_BYTES") && !getenv("ORIP_CCL_BYTES")) ORIP_TRY(orip_ccl_bits(c, LN(c).vtmp[10].as<unsigned long long>(), c->tmpD.as<int>(), K));
     else ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
     // ---- ordered compaction
     const int nblk = cdiv(n, 1024);

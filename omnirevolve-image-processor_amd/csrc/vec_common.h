@@ -601,6 +601,7 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v)
 // distance is below the squared gap between the cursor and the nearest unscanned cell (every unscanned entry is at least that far,
 // so it can neither win nor tie), or the window covers the grid.  The chain of steps is strictly serial and a step looks at a few
 // dozen entries, so ONE wavefront runs it: no barriers, no cross-wave exchange, and no other wave competing for the SIMD.
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_NN_OLDGRID / ORIP_NN_DBG): variants build only (make variants)
 __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict__ ends, int n, const int* __restrict__ sel, int skip_if, int need_any, int rule07, int G,
                                                         int32_t* __restrict__ order, uint8_t* __restrict__ flips, unsigned long long* __restrict__ dbg) {
     ORIP_NN_GATE(sel, skip_if, need_any)
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     { const int done = n & ~63; if (done + lane < n) { const unsigned v = ring[lane]; order[done + lane] = (int32_t)(v >> 1); flips[done + lane] = (uint8_t)(v & 1u); } }
     if (dbg && lane == 0) { dbg[0] = d_rounds; dbg[1] = d_scanned; dbg[2] = d_full; dbg[3] = (unsigned long long)cs; }
 }
+#endif
 // bit 0: some coordinate does not fit int16 (no LDS variant); bit 1: some coordinate outside [-2^14, 2^14) (no grid variant)
 __global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
     int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -938,12 +940,12 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "s_lshl_b32 s87, 1, %[sh]\n\t"                              // cell
         "s_add_i32 s88, s87, -1\n\t"                                // cell - 1
         "s_add_i32 s79, s87, 1\n\t"
-        "s_mul_i32 s100, s79, s79\n\t"
-        "s_lshr_b32 s80, s100, 18\n\t"
-        "s_sub_i32 s100, s100, s80\n\t"
-        "s_add_i32 s100, s100, -1\n\t"                              // the gap test's threshold for the smallest gap a 3x3 window can have (cell + 1)
+        "s_mul_i32 s59, s79, s79\n\t"
+        "s_lshr_b32 s80, s59, 18\n\t"
+        "s_sub_i32 s59, s59, s80\n\t"
+        "s_add_i32 s59, s59, -1\n\t"                              // the gap test's threshold for the smallest gap a 3x3 window can have (cell + 1)
         "s_mov_b32 s81, -1\n\t"                                     // cell the range words in s67 .. s76 belong to: none yet
-        "s_mov_b32 s99, 0\n\t"                                      // 1: the lanes hold the candidates of that cell's window (v45, v49, v51, v[52:53], s[92:93])
+        "s_mov_b32 s58, 0\n\t"                                      // 1: the lanes hold the candidates of that cell's window (v45, v49, v51, v[52:53], s[92:93])
         "v_cvt_f32_i32 v40, %[cx]\n\t"
         "v_cvt_f32_i32 v41, %[cy]\n\t"
         "L_step%=:\n\t"
@@ -955,7 +957,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "s_cbranch_scc1 L_samecell%=\n\t"
         // ---- another cell: the window's range words
         "s_mov_b32 s81, s79\n\t"
-        "s_mov_b32 s99, 0\n\t"
+        "s_mov_b32 s58, 0\n\t"
         "s_sub_i32 s62, s60, 1\n\t"
         "s_max_i32 s62, s62, 0\n\t"                                 // x0
         "s_add_i32 s63, s60, 1\n\t"
@@ -992,9 +994,9 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "s_nop 1\n\t"
         "s_branch L_ranges%=\n\t"
         "L_samecell%=:\n\t"                                          // the lanes may still hold this window's candidates: then no LDS read at all
-        "s_cmp_eq_u32 s99, 1\n\t"
+        "s_cmp_eq_u32 s58, 1\n\t"
         "s_cbranch_scc1 L_hit1%=\n\t"
-        "s_cmp_eq_u32 s99, 2\n\t"
+        "s_cmp_eq_u32 s58, 2\n\t"
         "s_cbranch_scc1 L_hit2%=\n\t"
         "L_ranges%=:\n\t"
         "s_cmp_eq_u32 s74, 0\n\t"
@@ -1007,7 +1009,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "v_cmp_gt_u32_e64 s[92:93], s74, %[lane]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         ORIP_NN_FETCH("v49", "v45", "v51", "52", "53")
-        "s_mov_b32 s99, 1\n\t"
+        "s_mov_b32 s58, 1\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "L_key%=:\n\t"
         ORIP_NN_KEY("v45", "v59", "52", "53", "s[92:93]")
@@ -1027,7 +1029,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "s_waitcnt lgkmcnt(0)\n\t"
         ORIP_NN_FETCH("v66", "v70", "v65", "68", "69")
         ORIP_NN_FETCH("v76", "v71", "v73", "74", "75")
-        "s_mov_b32 s99, 2\n\t"
+        "s_mov_b32 s58, 2\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "L_key2%=:\n\t"
         ORIP_NN_KEY("v70", "v67", "68", "69", "s[92:93]")
@@ -1042,7 +1044,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         // ---- more than 128: 128 per turn, the two halves' LDS reads in flight together; nothing is kept
         "L_loop%=:\n\t"
         "s_add_i32 %[cnt], %[cnt], 0x100000\n\t"
-        "s_mov_b32 s99, 0\n\t"
+        "s_mov_b32 s58, 0\n\t"
         "s_mov_b32 s98, 0\n\t"
         "v_mov_b32 v58, -1\n\t"
         "v_mov_b32 v59, -1\n\t"
@@ -1096,7 +1098,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "s_cbranch_scc1 L_fb5%=\n\t"
         "v_cvt_u32_f32 v48, s77\n\t"
         "v_add_u32 v48, 1, v48\n\t"
-        "v_cmp_ge_u32 vcc, s100, v48\n\t"
+        "v_cmp_ge_u32 vcc, s59, v48\n\t"
         "s_and_b64 s[94:95], vcc, exec\n\t"
         "s_cbranch_scc0 L_gap%=\n\t"
         "L_gapok%=:\n\t"
@@ -1122,7 +1124,7 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         "v_writelane_b32 %[ringv], s85, m0\n\t"
         // the lanes' copies of the winner's end points (its other entry may sit in this window too) take the flag as well
         "s_lshr_b32 s79, s85, 1\n\t"
-        "s_cmp_eq_u32 s99, 2\n\t"
+        "s_cmp_eq_u32 s58, 2\n\t"
         "s_cbranch_scc1 L_upd2%=\n\t"
         "v_lshrrev_b32 v50, 1, v49\n\t"
         "v_or_b32 v55, 0x8000, v52\n\t"
@@ -1195,8 +1197,8 @@ __device__ __forceinline__ int nn_asm_steps(int& cx, int& cy, int& step, unsigne
         : [n] "s"(s_n), [sh] "s"(s_sh), [G] "s"(s_G), [Gm1] "s"(s_Gm1), [cstb] "s"(s_cst), [eidb] "s"(s_eid), [pb] "s"(s_p), [nem1] "s"(s_nem1),
           [rowoff] "v"(rowoff), [isend] "v"(isend), [lane] "v"(lane)
         : "vcc", "scc", "memory",
-          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
-          "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100",
+          "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
+          "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98",
           "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
           "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77");
 #undef ORIP_NN_Q
@@ -1426,7 +1428,9 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     static std::atomic<int> attr_err{0};
     std::call_once(attr_once, [] {
         orip_max_lds(k_greedy_nn_lds, 150 * 1024, attr_err);
+#ifdef ORIP_VARIANTS
         orip_max_lds(k_greedy_nn_grid, 158 * 1024, attr_err);
+#endif
         orip_max_lds(k_greedy_nn_fast, 158 * 1024, attr_err);
     });
     if (attr_err.load()) ORIP_FAIL(c, "hipFuncSetAttribute(greedy kernels) failed: %s", hipGetErrorString((hipError_t)attr_err.load()));
@@ -1438,16 +1442,20 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     const int r07 = kind == 7 ? 1 : 0;
     {
         ProfScope ps(c, "k_greedy_nn");
-        unsigned long long* dbg = getenv("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
         if (grid_ok) {
-            if (dbg || getenv("ORIP_NN_OLDGRID")) hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, dbg);
-            else {
+#ifdef ORIP_VARIANTS
+            unsigned long long* dbg = ORIP_VARIANT("ORIP_NN_DBG") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
+            if (dbg || ORIP_VARIANT("ORIP_NN_OLDGRID")) {
+                hipLaunchKernelGGL(k_greedy_nn_grid, dim3(1), dim3(64), lds_grid, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, dbg);
+                if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
+            } else
+#endif
+            {
                 unsigned long long* dbg2 = getenv("ORIP_NN_DBG2") ? LN(c).flags.as<unsigned long long>() + 64 : nullptr;
                 if (dbg2) hipMemsetAsync(dbg2, 0, 80, LN(c).stream);
                 hipLaunchKernelGGL(k_greedy_nn_fast, dim3(1), dim3(64), lds_grid + 4, LN(c).stream, ends, (int)n, d_seed, 3, 0, r07, G, order, flips, getenv("ORIP_NN_NOASM") ? 1 : 0, dbg2);
                 if (dbg2) { unsigned long long h[10]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg2, 80, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg2] kind %d n %lld G %d: %llu steps by the compiled code (empty %llu, all used %llu, gap %llu; asm steps from cached candidates: one per lane %llu, two per lane %llu; with more than 128 candidates %llu), %llu asm entries, cycles asm %llu compiled %llu\n", kind, (long long)n, G, h[0], h[5], h[7], h[8], h[4], h[6], h[9], h[1], h[2], h[3]); hipMemsetAsync(dbg2, 0, 80, LN(c).stream); }
             }
-            if (dbg) { unsigned long long h[4]; hipStreamSynchronize(LN(c).stream); hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost); fprintf(stderr, "[nn dbg] kind %d n %lld G %d cell %llu: rounds %llu scanned %llu full %llu\n", kind, (long long)n, G, h[3], h[0], h[1], h[2]); }
         }
         // Behind the grid kernel only ONE more launch, and a light one (256 threads, no dynamic LDS): a kernel that merely checks its flag and
         // returns still waits for a CU with room for its whole workgroup -- 0.5 ms for 1024 threads or 150 KB of LDS next to the other layers' work.

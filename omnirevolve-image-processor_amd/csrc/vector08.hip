@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict
 }
 
 // ================================================================= A2: resample (08:53-64)
+// (preprocessor conditionals cannot sit inside ORIP_WITH_SRC's macro argument: the variants build's launch of the serial-chain form is a macro of its own)
+#ifdef ORIP_VARIANTS
+#define ORIP_CUM_CHAIN_LAUNCH(SRC_T) if (ORIP_VARIANT("ORIP_CUM_CHAIN")) { chain = true; hipLaunchKernelGGL((k_cumlen_long2<SRC_T, true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }
+#else
+#define ORIP_CUM_CHAIN_LAUNCH(SRC_T)
+#endif
 #define ORIP_LONG_CUM 128      // polylines above this many points get a wavefront for their cumulative lengths (k_cumlen_long2)
 struct RsInfo { int64_t n_eff; double total; unsigned m; unsigned pass; };
 // sequential float32 cumsum per polyline (np.cumsum): one lane per short polyline; long polylines (k_cumlen_long2) use one
@@ -437,6 +443,7 @@ __device__ __forceinline__ double rl_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_TAIL_OLDSIM): variants build only (make variants)
 __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sbase, int64_t n_rank, double tail_len_px, SampleArrs A, unsigned* __restrict__ npop, const unsigned* __restrict__ only) {
     __shared__ double ring[2048];
     __shared__ unsigned npst[1024 + 64];
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(64) void k_tail_sim(const unsigned* __restrict__ sb
         flush(cs, m - cs);
     }
 }
+#endif
 // ---- the sequential simulation, replayed.  k_tail_par leaves for every sample the head the queue WOULD have if every comparison were
 // decided by exact arithmetic; the reference decides them with a float64 running sum whose roundings depend on the whole history of pushes
 // and pops.  Given the heads, that history is a fixed list of operations (+d[j], then -d[h] for every popped h), and its value after every
@@ -956,13 +964,16 @@ __global__ __launch_bounds__(256) void k_stamp_groups(const int64_t* __restrict_
     }
 }
 // mask of the stamped raster + list of the 64x4 tiles that hold foreground (thinning only ever clears pixels, so the other tiles stay empty)
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_gid_to_mask(const unsigned* __restrict__ gid, u8* __restrict__ m, int H, int W, unsigned* __restrict__ tiles, unsigned* __restrict__ ntiles) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     int fg = 0;
     if (x < W && y < H) { size_t o = (size_t)y * W + x; fg = gid[o] ? 1 : 0; m[o] = fg ? 255 : 0; }
     if (__syncthreads_or(fg) && threadIdx.x == 0) tiles[atomicAdd(ntiles, 1u)] = blockIdx.y * gridDim.x + blockIdx.x;
 }
+#endif
 // standard-orientation Zhang-Suen sub-iteration (08:349-366) over the listed tiles
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __restrict__ d, int H, int W, int sub, int* __restrict__ changed,
                                                  const unsigned* __restrict__ tiles, const unsigned* __restrict__ ntiles, int gx) {
     const unsigned nt = *ntiles;
@@ -983,6 +994,7 @@ __global__ __launch_bounds__(256) void k_zs_sub(const u8* __restrict__ s, u8* __
         d[o] = v ? 255 : 0;
     }
 }
+#endif
 // ---- the same thinning on bit planes (one bit per pixel, 64 pixels per word; the padded canvas is 12.8 MB, i.e. cache-resident).
 // A sub-iteration evaluates the Zhang-Suen conditions for 64 pixels at once with bit-sliced logic: the eight neighbour planes come
 // from the three rows by word shifts, B = P2+...+P9 from a carry-save adder tree, A == 1 ("exactly one 0->1 transition") from a
@@ -1047,11 +1059,14 @@ __global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __res
     d[wi] = M & ~del;
 }
 // plain (linear id) union-find CCL on the padded raster
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_ccl2_init(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     int id = y * W + x; if (s[id]) L[id] = id;          // background parents are never read: not written either
 }
+#endif
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, int* __restrict__ L, int H, int W) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -1064,7 +1079,10 @@ __global__ __launch_bounds__(256) void k_ccl2_merge(const u8* __restrict__ s, in
         if (x + 1 < W && s[id - W + 1]) uunite(L, id, id - W + 1);
     }
 }
+#endif
+#ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
 __global__ __launch_bounds__(256) void k_ccl2_flatten(const u8* __restrict__ s, int* __restrict__ L, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n && s[i]) L[i] = ufind(L, i); }
+#endif
 // the same union-find driven from the thinned bit plane: a thread owns a 64-pixel word, returns at once when it is empty (the
 // skeleton fills ~1 % of the canvas) and walks its set bits otherwise.  mode 0: init, 1: merge, 2: flatten.
 __global__ __launch_bounds__(256) void k_ccl2_bits(const unsigned long long* __restrict__ bits, int* __restrict__ L, int H, int W, int Ww, int mode) {
@@ -1492,11 +1510,13 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(2 * n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
-        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
-            const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 1);
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 1);
             for (int dir = 0; dir < 2; dir++) {          // forward, then (reading what forward stored) reversed
-                if (chain) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
-                else hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
+#ifdef ORIP_VARIANTS
+                if (ORIP_VARIANT("ORIP_CUM_CHAIN")) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
+                else
+#endif
+                hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
             } }
         ORIP_TRY(vfeatures_long(c, sS, n, total, 1 | 16 | 32, ff, per_rev, seg));
         HIPC(c, hipGetLastError());
@@ -1614,10 +1634,10 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         } else {
         HIPC(c, hipMemcpyAsync(cumoff, kept0.p.off.p, (size_t)(nk + 1) * 8, hipMemcpyDeviceToDevice, LN(c).stream));
         { ProfScope ps(c, "k_cumlen"); ORIP_WITH_SRC(c, kept0.p, sv, { hipLaunchKernelGGL(k_cumlen<decltype(sv)>, dim3(cdiv(nk, 128)), dim3(128), 0, LN(c).stream, sv, nk, step, cum, info); }); }
-        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const bool chain = getenv("ORIP_CUM_CHAIN") != nullptr;
-            ORIP_WITH_SRC(c, kept0.p, sv, {
-                if (chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr);
-                else hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }); }
+        if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, {
+                bool chain = false;
+                ORIP_CUM_CHAIN_LAUNCH(decltype(sv))
+                if (!chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }); }
         }
         tick("cumlen");
         HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));
@@ -1667,8 +1687,11 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 // the sequential redo only feeds the acceptance test (A6): it runs on the lane's side stream under the capsule / hash work
                 HIPC(c, hipEventRecord(LN(c).ev2, LN(c).stream));
                 HIPC(c, hipStreamWaitEvent(LN(c).stream2, LN(c).ev2, 0));
-                if (getenv("ORIP_TAIL_OLDSIM")) hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
-                else hipLaunchKernelGGL(k_tail_replay, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
+#ifdef ORIP_VARIANTS
+                if (ORIP_VARIANT("ORIP_TAIL_OLDSIM")) hipLaunchKernelGGL(k_tail_sim, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
+                else
+#endif
+                hipLaunchKernelGGL(k_tail_replay, dim3((unsigned)std::min<int64_t>(nk, 65535)), dim3(64), 0, LN(c).stream2, sbase, nk, P.tail_len_px, A, npop, only);
                 HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream2));
             }
             if (any_out)
@@ -1786,8 +1809,8 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         HIPC(c, LN(c).vtmp[9].ensure(Np * 2 + ntile_max * 4 + nwords * 16 + 256));
         u8* skA = LN(c).vtmp[9].as<u8>(); u8* skB = skA + Np; unsigned* tiles = (unsigned*)(skB + ((Np + 15) & ~(size_t)15));
         unsigned long long* bA = (unsigned long long*)(tiles + ((ntile_max + 3) & ~(size_t)3)); unsigned long long* bB = bA + nwords;
-        int* d_changed = LN(c).flags.as<int>() + 48; unsigned* d_ntiles = LN(c).flags.as<unsigned>() + 52;
-        if (!getenv("ORIP_THIN_BYTES")) {
+        int* d_changed = LN(c).flags.as<int>() + 48; unsigned* d_ntiles = LN(c).flags.as<unsigned>() + 52; (void)d_changed; (void)d_ntiles;      // (byte-plane thinning: variants build)
+        if (!ORIP_VARIANT("ORIP_THIN_BYTES")) {
             const dim3 gwd((unsigned)cdiv((int64_t)nwords, 256));
             hipLaunchKernelGGL(k_gid_to_bits, gwd, blk, 0, LN(c).stream, gid, bA, Hp, Wp, Wwp);      // 4 waves x 64 words per block
             tick("raster");
@@ -1808,7 +1831,9 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
                 it += nb;
             }
             hipLaunchKernelGGL(k_bits_to_mask, gwd, blk, 0, LN(c).stream, bA, skA, Hp, Wp, Wwp);
-        } else {
+        }
+#ifdef ORIP_VARIANTS
+        else {
         HIPC(c, hipMemsetAsync(d_ntiles, 0, 4, LN(c).stream));
         HIPC(c, hipMemsetAsync(skB, 0, Np, LN(c).stream));
         hipLaunchKernelGGL(k_gid_to_mask, g2, blk, 0, LN(c).stream, gid, skA, Hp, Wp, tiles, d_ntiles);
@@ -1822,20 +1847,24 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             if (!ch) break;
         }
         }
+#endif
         tick("thin");
         // components
         HIPC(c, LN(c).vtmp[10].ensure(Np * 4 + 64));
         int* L2 = LN(c).vtmp[10].as<int>();
-        if (!getenv("ORIP_THIN_BYTES")) {      // bA holds the thinned bit plane
+        if (!ORIP_VARIANT("ORIP_THIN_BYTES")) {      // bA holds the thinned bit plane
             const dim3 gwd((unsigned)cdiv((int64_t)nwords, 256));
             hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 0);
             { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 1); }
             hipLaunchKernelGGL(k_ccl2_bits, gwd, blk, 0, LN(c).stream, bA, L2, Hp, Wp, Wwp, 2);
-        } else {
+        }
+#ifdef ORIP_VARIANTS
+        else {
         hipLaunchKernelGGL(k_ccl2_init, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp);
         { ProfScope ps(c, "k_ccl2_merge"); hipLaunchKernelGGL(k_ccl2_merge, g2, blk, 0, LN(c).stream, skA, L2, Hp, Wp); }
         hipLaunchKernelGGL(k_ccl2_flatten, dim3(cdiv(Np, 256)), blk, 0, LN(c).stream, skA, L2, (int)Np);
         }
+#endif
         tick("c:ccl");
         const int nblk = cdiv((int64_t)Np, 1024);
         HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));

@@ -7,6 +7,9 @@ import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "liborip.so")
+# ORIP_LIB_VARIANTS=1: the variants build (`make -C csrc variants`: the same sources plus the replaced kernel variants, for the agreement tests)
+if os.environ.get("ORIP_LIB_VARIANTS") == "1" and os.path.exists(os.path.join(_PKG, "liborip_variants.so")):
+    LIB_PATH = os.path.join(_PKG, "liborip_variants.so")
 
 # One hardware queue per lane (layer pipelines, raster stages, stage 10): HIP multiplexes its streams onto GPU_MAX_HW_QUEUES
 # (default 4) hardware queues and kernels sharing a queue run one after the other, so a short kernel of one layer would wait
@@ -58,6 +61,7 @@ SIGNATURES = {
     "orip_dedup_layer": (_i32, [_vp, _i32, _P(Params08)]), "orip_layer_front": (_i32, [_vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]), "orip_dedup_cross": (_i32, [_vp, _vp, _i32, _P(Params10)]),
     "orip_plot_order": (_i32, [_vp, _i32, _f64, _P(_i64)]), "orip_get_ops": (_i32, [_vp, _i32, _vp]),
     "orip_preview_cover": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "orip_has_variants": (_i32, []),
     "orip_stream_codes": (_i32, [_vp, _vp, _i64, _P(_i64)]), "orip_stream_codes_fetch": (_i32, [_vp, _vp, _vp]),
     "orip_comm_unique_id": (_i32, [_vp]), "orip_comm_init": (_i32, [_vp, _vp, _i32, _i32]), "orip_comm_destroy": (_i32, [_vp]),
     "orip_bcast_layer": (_i32, [_vp, _i32, _i32]),
@@ -81,3 +85,8 @@ def load():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def has_variants() -> bool:
+    """True when the loaded library carries the replaced kernel variants (include/orip.h: orip_has_variants)."""
+    return bool(load().orip_has_variants())

@@ -58,8 +58,10 @@ def test_kmeans_random_pixels_matches_oracle(dev):
 
 
 def test_kmeans_both_kernels_agree(dev, monkeypatch):
-    """The fit runs spread over 64 workgroups with a device-wide barrier; the single-workgroup version it replaced is kept
-    behind ORIP_KMEANS_1WG.  Same centres and the same compactness (fixed reduction tree), also with a cluster that empties."""
+    """The fit runs spread over groups of 64 workgroups with a device-wide barrier each; the single-workgroup version it replaced is kept
+    behind ORIP_KMEANS_1WG in the variants build (`make -C csrc variants`, ORIP_LIB_VARIANTS=1).  Same centres and the same compactness (fixed
+    reduction tree), also with a cluster that empties.  With the default library the switch reads as not set: both fits are the same kernel and
+    the comparison with the oracle below is what the test holds."""
     rng = np.random.default_rng(11)
     for img, K in [(rng.integers(0, 256, (120, 150, 3), dtype=np.uint8), 7),
                    (np.repeat(rng.integers(0, 256, (3, 1, 3), dtype=np.uint8), 4000, axis=1).reshape(100, 120, 3), 6)]:
