@@ -483,7 +483,7 @@ __device__ __forceinline__ float nn_d2(int32_t ax, int32_t ay, int32_t bx, int32
     float dx = __fsub_rn((float)ax, (float)bx), dy = __fsub_rn((float)ay, (float)by);
     return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
 }
-// sel[0] = seed polyline, sel[1] = coordinate-range flags of k_ends_fit16 (both written on the device just before: the host does not wait for
+// sel[0] = seed polyline, sel[1] = coordinate-range flags (k_argmax_feat: bit 0 some coordinate beyond int16 -> no LDS variant, bit 1 beyond 15 bits -> no grid variant; both written on the device just before: the host does not wait for
 // them).  The candidates are all enqueued and each decides from sel[1] whether it is the one that runs: (flags & skip_if) != 0 -> not
 // this one; need_any != 0 && (flags & need_any) == 0 -> not this one either.
 #define ORIP_NN_GATE(sel, skip_if, need_any) const int fl_ = (sel)[1]; if ((fl_ & (skip_if)) != 0 || ((need_any) != 0 && (fl_ & (need_any)) == 0)) return; const int seed = (sel)[0];
@@ -720,14 +720,6 @@ __global__ __launch_bounds__(64) void k_greedy_nn_grid(const NNEnds* __restrict_
     if (dbg && lane == 0) { dbg[0] = d_rounds; dbg[1] = d_scanned; dbg[2] = d_full; dbg[3] = (unsigned long long)cs; }
 }
 #endif
-// bit 0: some coordinate does not fit int16 (no LDS variant); bit 1: some coordinate outside [-2^14, 2^14) (no grid variant)
-__global__ __launch_bounds__(256) void k_ends_fit16(const NNEnds* __restrict__ e, int n, int* __restrict__ bad) {
-    int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
-    NNEnds q = e[i];
-    auto out = [&](int lo, int hi) { return q.sx < lo || q.sx > hi || q.sy < lo || q.sy > hi || q.ex < lo || q.ex > hi || q.ey < lo || q.ey > hi; };
-    if (out(-32768, 32767)) atomicOr(bad, 1);
-    if (out(-16384, 16383)) atomicOr(bad, 2);        // the grid variant keeps origin-relative coordinates in 15 bits
-}
 
 // ---- descriptor-driven gather: output polyline k = src points [begin[k], begin[k]+len[k]) (reversed if rev[k]) ----
 struct GatherDesc { int64_t begin; int64_t len; int32_t rev; int32_t src; };     // src: index of the source polyline (walk-coded sources are addressed by polyline, not by point)
@@ -834,10 +826,22 @@ __global__ __launch_bounds__(256) void k_desc_from_order(const int64_t* __restri
 }
 
 // argmax with first-max tie-break over a float / double field of PolyFeat (seed of the greedy orders); tiny: single block
-__global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict__ f, int n, int use_arc, int* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict__ f, int n, int use_arc, int* __restrict__ out, const NNEnds* __restrict__ e = nullptr) {
     __shared__ double bv[1024]; __shared__ int bi[1024];
-    double v = -1.0; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 1024) { double x = use_arc ? f[i].arc : (double)f[i].per; if (x > v) { v = x; idx = i; } }
+    __shared__ int bad_s;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    double v = -1.0; int idx = 0x7fffffff; int bad = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double x = use_arc ? f[i].arc : (double)f[i].per; if (x > v) { v = x; idx = i; }
+        if (e) {      // the coordinate-range flags of the greedy kernels in the same pass (k_ends_fit16's: bit 0 beyond int16, bit 1 beyond 15 bits): out[1]
+            const NNEnds q = e[i];
+            auto outside = [&](int lo, int hi) { return q.sx < lo || q.sx > hi || q.sy < lo || q.sy > hi || q.ex < lo || q.ex > hi || q.ey < lo || q.ey > hi; };
+            if (outside(-32768, 32767)) bad |= 1;
+            if (outside(-16384, 16383)) bad |= 2;
+        }
+    }
+    if (bad) atomicOr(&bad_s, bad);
     bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = bi[0];
+    if (threadIdx.x == 0) { *out = bi[0]; if (e) out[1] = bad_s; }
 }
 template <class Src>
 __global__ __launch_bounds__(256) void k_ends_from_feat(const PolyFeat* __restrict__ f, int64_t n, int rule07, Src src, NNEnds* __restrict__ e) {
@@ -1416,9 +1420,7 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     } else ORIP_TRY(vfeatures(c, src, what, feat));
     ORIP_WITH_SRC(c, src, ps, { hipLaunchKernelGGL(k_ends_from_feat<decltype(ps)>, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, ps, ends); });
     int* d_seed = LN(c).flags.as<int>() + 32;
-    HIPC(c, hipMemsetAsync(d_seed + 1, 0, 4, LN(c).stream));
-    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed);
-    hipLaunchKernelGGL(k_ends_fit16, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, ends, (int)n, d_seed + 1);
+    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed, ends);      // seed and coordinate-range flags in one pass
     const size_t lds = (size_t)n * 9 + 16;
     // grid side: as fine as LDS allows (cells are powers of two, so twice the side is four times fewer candidates per window),
     // but not many more cells than polylines
