@@ -27,7 +27,7 @@ extern "C" int orip_create(int device_id, orip_ctx** out) {
         if (hipStreamCreate(&l.stream) != hipSuccess) { delete c; return -5; }
         hipEventCreate(&l.ev0); hipEventCreate(&l.ev1);
         if (hipStreamCreate(&l.stream2) != hipSuccess) { delete c; return -5; }
-        hipEventCreateWithFlags(&l.ev2, hipEventDisableTiming); hipEventCreateWithFlags(&l.ev3, hipEventDisableTiming);
+        hipEventCreateWithFlags(&l.ev2, hipEventDisableTiming); hipEventCreateWithFlags(&l.ev3, hipEventDisableTiming); hipEventCreateWithFlags(&l.ev4, hipEventDisableTiming);
         if (l.flags.ensure(4096) != hipSuccess) { delete c; return -6; }
         hipMemsetAsync(l.flags.p, 0, 4096, l.stream);
         hipStreamSynchronize(l.stream);
@@ -50,6 +50,7 @@ extern "C" void orip_destroy(orip_ctx* c) {
         if (l.ev1) hipEventDestroy(l.ev1);
         if (l.ev2) hipEventDestroy(l.ev2);
         if (l.ev3) hipEventDestroy(l.ev3);
+        if (l.ev4) hipEventDestroy(l.ev4);
         if (l.stream2) hipStreamDestroy(l.stream2);
         if (l.stream) hipStreamDestroy(l.stream);
     }
@@ -122,6 +123,8 @@ extern "C" int orip_set_polys(orip_ctx* c, int slot, int layer, int64_t n, const
     if (n < 0) ORIP_FAIL(c, "negative count");
     DPolys& P = c->polys[slot][layer];
     int64_t total = n ? off[n] : 0;
+    { LaneRes::Prefetch08& F = c->ln[layer + 1].pf08;       // a prefetch of stage 08 still reading this layer's lists on its side stream: let it finish first
+      if (F.pending) { HIPC(c, hipEventSynchronize(c->ln[layer + 1].ev3)); } }
     HIPC(c, P.off.ensure((size_t)(n + 1) * 8 + 64));
     HIPC(c, P.pts.ensure((size_t)std::max<int64_t>(total, 1) * 8 + 64));
     if (n) HIPC(c, hipMemcpyAsync(P.off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, LN(c).stream));

@@ -111,7 +111,7 @@ struct ProfEntry { double ms = 0; int64_t launches = 0; };
 struct LaneRes {
     hipStream_t stream = 0;
     hipStream_t stream2 = 0;              // side stream of the lane (work that may overlap the main chain), fenced with ev2 / ev3
-    hipEvent_t ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;   // (ev4 / ev3: features / everything of stage 08's prefetch)
     DBuf vtmp[12], tmpE, tmpF, flags, canvas;
     DBuf pixbits;                         // stage 08-A: one bit per canvas pixel that is the rounded position of a sample
     unsigned caps_hint = 0;               // distinct capsules of the lane's last stage-08-A run (sizes the next run's table)
@@ -119,9 +119,10 @@ struct LaneRes {
     DPolys tp[6];   // persistent temporaries of the vector stages (no hipFree in steady state: hipFree synchronises the device)
     // stage 08's order-independent front, computed on the side stream while stage 07's greedy chain runs (vector08.hip: prefetch08)
     struct Prefetch08 {
+        bool pending = false;          // side-stream work the lane's main stream has not waited for yet (orip_pf08_drain)
         bool valid = false; uint64_t tag = 0; int64_t n = 0; int64_t tot_f = 0; double step = 0;
         const int64_t* src_off = nullptr;   // offsets of the list it was computed on (device): both readings of polyline i keep their cumulative lengths at src_off[i]
-        DBuf seg;                      // float32 length of every segment of the list (k_cumlen_long2 forward -> reversed reading, perimeter sums)
+        DBuf seg;                      // float32 length of every segment of the list (k_seglen -> both readings, perimeter sums)
         DBuf feat, info, cum, ord;     // PolyFeat[n] + reversed perimeters float[n]; RsInfo[2n]: forward at i, reversed at n + i; cum: forward readings, then (tot_f on) reversed
     } pf08;
 };
@@ -142,9 +143,14 @@ struct LaneGuard {
     LaneGuard(orip_ctx* ctx, int lane_id);
     ~LaneGuard();
 };
-#define ORIP_LANE(ctx, lane_id)                                                                                              \
+#define ORIP_LANE_NODRAIN(ctx, lane_id)                                                                                      \
     LaneGuard _lane_guard((ctx), (lane_id));                                                                                 \
     if (!_lane_guard.ok) ORIP_FAIL(ctx, "lane %d is busy: another call is using this layer's stream and scratch", (int)(lane_id))
+// Stage 08's prefetch (vector08.hip: prefetch08) may still be running on the lane's side stream when stage 07 returns: stage 08 waits for its parts where it
+// consumes them; every other call that claims the lane puts its main stream behind the whole of it first (it reads the scaled list and the lane's scratch).
+#define ORIP_LANE(ctx, lane_id)                                                                                              \
+    ORIP_LANE_NODRAIN(ctx, lane_id);                                                                                         \
+    HIPC(ctx, orip_pf08_drain(ctx))
 
 struct orip_ctx {
     int device = 0;
@@ -191,6 +197,12 @@ struct orip_ctx {
 inline LaneGuard::LaneGuard(orip_ctx* ctx, int lane_id) : c(ctx), prev(orip_tls_lane), lane(lane_id), ok(true), owner(false) {
     if (prev != lane) { int expect = 0; ok = c->lane_owner[lane].compare_exchange_strong(expect, 1); owner = ok; }
     if (ok) orip_tls_lane = lane;
+}
+inline hipError_t orip_pf08_drain(orip_ctx* c) {           // the claimed lane's main stream goes on behind its pending prefetch
+    LaneRes& l = LN(c);
+    if (!l.pf08.pending) return hipSuccess;
+    l.pf08.pending = false;
+    return hipStreamWaitEvent(l.stream, l.ev3, 0);
 }
 inline LaneGuard::~LaneGuard() { if (ok) orip_tls_lane = prev; if (owner) c->lane_owner[lane].store(0); }
 

@@ -69,8 +69,8 @@ struct PolyFeat {
     uint8_t closed;             // first == last on the ORIGINAL polyline (n >= 2)
 };
 
-// (stage 08's prefetch takes the perimeters of polylines above this from the segment lengths k_cumlen_long2 stores for readings above ORIP_LONG_CUM = 128
-// points; a reading is at most two points shorter than the open view counted here, so the threshold must stay above 130)
+// (stage 08's prefetch keeps the segment lengths of polylines above ORIP_LONG_CUM = 128 points (k_seglen) and takes the perimeters of open views above
+// this threshold from them: it must not be below ORIP_LONG_CUM)
 #define ORIP_LONG_POLY 192
 // ---- where a list's points come from (vsrc.h): explicit array or the layer's walk records ----
 static inline ESrc esrc_of(const DPolys& P) { return ESrc{P.off.as<int64_t>(), reinterpret_cast<const int2*>(P.pts.p)}; }
@@ -178,7 +178,7 @@ __device__ __forceinline__ float pairwise_leaf_g8_rev(const int32_t* xy, int64_t
     for (int64_t i = lim; i < n; i++) r += el(i);
     return r;
 }
-// the same leaves over STORED segment lengths (sl[k] = float32 length of segment k; prefetch08: k_cumlen_long2 leaves them behind)
+// the same leaves over STORED segment lengths (sl[k] = float32 length of segment k; prefetch08: k_seglen)
 __device__ __forceinline__ float pairwise_leaf_f(const float* sl, int64_t s, int64_t n, int j) {
     const int64_t lim = n - (n % 8);
     float r = sl[s + j];
@@ -200,18 +200,17 @@ __device__ __forceinline__ float pairwise_leaf_f_rev(const float* sl, int64_t ns
 // The same leaf shape serves the forward sum and the sum over the reversed sequence (element i' of the reversed polyline = forward segment ns - 1 - i').
 // k_poly_features_long then only combines the leaves (what & 64): with one block per polyline staging the lengths through LDS the launch was as long as
 // ~7 rounds of 186 k-element polylines at five blocks per CU.
-__global__ __launch_bounds__(256) void k_perim_leaves_seg(const int64_t* __restrict__ off, int64_t n_polys, const PolyFeat* __restrict__ feat, const float* __restrict__ seg,
-                                                          float* __restrict__ leafbuf, float* __restrict__ leafbuf_rev, int64_t nslots) {
-    __shared__ int64_t i_first;
-    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; const int j = threadIdx.x & 7;
+__device__ __forceinline__ void perim_leaves_seg_block(int64_t vblock, int64_t* i_first, const int64_t* __restrict__ off, int64_t n_polys, const PolyFeat* __restrict__ feat,
+                                                       const float* __restrict__ seg, float* __restrict__ leafbuf, float* __restrict__ leafbuf_rev, int64_t nslots) {
+    const int64_t q = (vblock * 256 + threadIdx.x) >> 3; const int j = threadIdx.x & 7;
     if (threadIdx.x == 0) {                               // polyline of the block's first slot: the last i with (off[i] >> 6) + 2 i <= q; the other 31 slots walk on from it
         int64_t lo = 0, hi = n_polys - 1;
         while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((off[mid] >> 6) + 2 * mid <= q) lo = mid; else hi = mid - 1; }
-        i_first = lo;
+        *i_first = lo;
     }
     __syncthreads();
     if (q >= nslots) return;
-    int64_t i = i_first;
+    int64_t i = *i_first;
     while (i + 1 < n_polys && (off[i + 1] >> 6) + 2 * (i + 1) <= q) i++;
     const int64_t n = feat[i].n;
     if (n <= ORIP_LONG_POLY) return;
@@ -224,6 +223,11 @@ __global__ __launch_bounds__(256) void k_perim_leaves_seg(const int64_t* __restr
     const float v = pairwise_leaf_f(sl, s, len, j);
     if (j == 0) leafbuf[q] = v;
     if (leafbuf_rev) { const float r = pairwise_leaf_f_rev(sl, ns, s, len, j); if (j == 0) leafbuf_rev[q] = r; }
+}
+__global__ __launch_bounds__(256) void k_perim_leaves_seg(const int64_t* __restrict__ off, int64_t n_polys, const PolyFeat* __restrict__ feat, const float* __restrict__ seg,
+                                                          float* __restrict__ leafbuf, float* __restrict__ leafbuf_rev, int64_t nslots) {
+    __shared__ int64_t i_first;
+    perim_leaves_seg_block((int64_t)blockIdx.x, &i_first, off, n_polys, feat, seg, leafbuf, leafbuf_rev, nslots);
 }
 #define ORIP_PF_MARGIN 132      // points staged on either side of a turn's 2048: a leaf has at most 128 elements and owns a multiple of 64 of the turn
 template <class Src, bool FROM_SEG = false>
@@ -443,9 +447,9 @@ __global__ __launch_bounds__(64) void k_walk_arcs(VSrc src, int64_t n_polys, Pol
         if (lane == 0) feat[i].arc = acc;
     }
 }
-// the long polylines' part of vfeatures_src; seg != nullptr: their perimeters from stored segment lengths (what == 1 | 16 [| 32]; bounding boxes already in feat)
+// the long polylines' part of vfeatures_src
 template <class Src>
-static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev, const float* seg = nullptr) {
+static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total, int what, PolyFeat* feat, float* per_rev) {
     if (n == 0 || total <= ORIP_LONG_POLY) return 0;
     const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
     HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) * ((what & 32) ? 2 : 1) + (size_t)n * 16 + 64));
@@ -454,11 +458,7 @@ static int vfeatures_long(orip_ctx* c, const Src& src, int64_t n, int64_t total,
     hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.off, n, kin, vin);
     ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, vout, (size_t)n, 0, 32, true)));
     ProfScope ps(c, "k_poly_features_long");
-    if (seg) {
-        hipLaunchKernelGGL(k_perim_leaves_seg, dim3((unsigned)cdiv((int64_t)nleaf * 8, 256)), dim3(256), 0, LN(c).stream, src.off, n, feat, seg, leafbuf, leafbuf_rev, (int64_t)nleaf);
-        hipLaunchKernelGGL((k_poly_features_long<Src, true>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what | 64, feat, leafbuf, vout, per_rev, leafbuf_rev, seg);
-    }
-    else hipLaunchKernelGGL((k_poly_features_long<Src, false>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, (const float*)nullptr);
+    hipLaunchKernelGGL((k_poly_features_long<Src, false>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, src, n, what, feat, leafbuf, vout, per_rev, leafbuf_rev, (const float*)nullptr);
     HIPC(c, hipGetLastError());
     return 0;
 }

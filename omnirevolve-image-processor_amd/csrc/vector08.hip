@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_compact_desc(const unsigned* __restrict
 // ================================================================= A2: resample (08:53-64)
 // (preprocessor conditionals cannot sit inside ORIP_WITH_SRC's macro argument: the variants build's launch of the serial-chain form is a macro of its own)
 #ifdef ORIP_VARIANTS
-#define ORIP_CUM_CHAIN_LAUNCH(SRC_T) if (ORIP_VARIANT("ORIP_CUM_CHAIN")) { chain = true; hipLaunchKernelGGL((k_cumlen_long2<SRC_T, true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }
+#define ORIP_CUM_CHAIN_LAUNCH(SRC_T) if (ORIP_VARIANT("ORIP_CUM_CHAIN")) { chain = true; hipLaunchKernelGGL((k_cumlen_long2<SRC_T, true>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (const float*)nullptr); }
 #else
 #define ORIP_CUM_CHAIN_LAUNCH(SRC_T)
 #endif
@@ -194,26 +194,21 @@ __device__ __forceinline__ int2 lane_succ(const int2 v, const int2 last, int lan
     if (lane == 63) r = last;
     return r;
 }
+// One wavefront reads one long polyline in one direction: slot-th of n_slots waves of that direction, longest polylines first (ord).
+// seg != nullptr (prefetch08): the float32 length of every segment is already there (k_seglen), so a reading costs 4 bytes per segment instead of
+// turning (polyline, index) into a point again (~25 instructions; the launches are bound by instruction issue).
 template <class Src, bool CHAIN>
-__global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
-                                                     int dir0, float* __restrict__ seg, PolyFeat* __restrict__ bb) {
-    const int lane = threadIdx.x;
-    const bool rev = ((blockIdx.y + (unsigned)dir0) & 1u) != 0;      // the reading direction: one wave per polyline and direction
-    for (int64_t rr = blockIdx.x; rr < n_polys; rr += gridDim.x) {
+__device__ __forceinline__ void cumlen_long_wave(const Src& src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info,
+                                                 const unsigned* __restrict__ ord, const bool rev, const float* __restrict__ seg, int64_t slot, int64_t n_slots, const int lane) {
+    for (int64_t rr = slot; rr < n_polys; rr += n_slots) {
         const int64_t i = ord[rr];
         RsInfo r = info[rev ? n_polys + i : i];
         if (r.n_eff <= ORIP_LONG_CUM) continue;
         auto cu = src.cur(i); const int64_t nfull = src.len(i);
         float* s = cum + (rev ? rev_off : 0) + src.off[i];
         const int64_t ns = r.n_eff - 1;                                             // segments; points 0 .. ns of this reading
-        // prefetch08 (seg != nullptr): the forward reading leaves the float32 length of EVERY segment of the polyline in seg (and the bounding box of
-        // its open view in bb) -- the reversed reading and the perimeter sums of stage 08 then read 4 bytes per segment instead of turning
-        // (polyline, index) into a point again (~25 instructions; the launches are bound by instruction issue)
-        float* sg = seg ? seg + src.off[i] : nullptr;
-        const bool from_seg = rev && sg && info[i].n_eff > ORIP_LONG_CUM;           // (the forward wave of this polyline has run: an earlier launch)
-        const int64_t nall = (sg && !rev) ? (nfull - 1 > ns ? nfull - 1 : ns) : ns; // segments whose length is computed here
-        const int64_t vn = (bb && !rev) ? bb[i].n : 0;                              // bounding box over the points [0, vn)
-        int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+        const float* sg = seg ? seg + src.off[i] : nullptr;                         // sg[k]: segment k of the FORWARD polyline, k < nfull - 1
+        const bool from_seg = sg != nullptr;
         float acc = 0.f; unsigned cE = 0u, cM = 0u;
         if (lane == 0) s[0] = 0.f;
         // A turn is 4 windows of 64 segment lengths.  Every point is fetched ONCE: the far end of segment k is the point in the next lane, the far end of a
@@ -223,11 +218,11 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
         auto request = [&](int64_t base, int2 (&p)[5], float (&fl)[4]) {
             if (from_seg) {
 #pragma unroll
-                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; fl[w] = k < ns ? sg[nfull - 2 - k] : 0.f; }
+                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; fl[w] = k < ns ? sg[rev ? nfull - 2 - k : k] : 0.f; }
             } else {
 #pragma unroll
-                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k <= nall ? P(k) : make_int2(0, 0); }
-                p[4] = base + 256 <= nall ? P(base + 256) : make_int2(0, 0);
+                for (int w = 0; w < 4; w++) { const int64_t k = base + 64 * w + lane; p[w] = k <= ns ? P(k) : make_int2(0, 0); }
+                p[4] = base + 256 <= ns ? P(base + 256) : make_int2(0, 0);
             }
         };
         auto lengths = [&](int64_t base, const int2 (&p)[5], const float (&fl)[4], float (&sl)[4]) {
@@ -243,14 +238,12 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
                 const int2 b2 = lane_succ(p[w], nx0, lane);
                 float dx = (float)b2.x - (float)p[w].x, dy = (float)b2.y - (float)p[w].y; float qx = dx * dx, qy = dy * dy;
                 const float L = sqrtf(qx + qy);                                        // seg_len_f32
-                if (sg && k < nall) sg[k] = L;
                 sl[w] = k < ns ? L : 0.f;                                              // beyond the last segment of this reading: +0
-                if (k < vn) { bx0 = min(bx0, p[w].x); bx1 = max(bx1, p[w].x); by0 = min(by0, p[w].y); by1 = max(by1, p[w].y); }
             }
         };
         int2 rp[5]; float rf[4] = {0.f, 0.f, 0.f, 0.f}; float cur[4];
         request(0, rp, rf); lengths(0, rp, rf, cur);
-        for (int64_t base = 0; base < nall; base += 256) {
+        for (int64_t base = 0; base < ns; base += 256) {
             request(base + 256, rp, rf);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -268,12 +261,55 @@ __global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, d
             }
             lengths(base + 256, rp, rf, cur);
         }
-        if (vn > 0) {
-            for (int o = 32; o > 0; o >>= 1) { bx0 = min(bx0, __shfl_xor(bx0, o, 64)); bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64)); }
-            if (lane == 0) { bb[i].x0 = bx0; bb[i].x1 = bx1; bb[i].y0 = by0; bb[i].y1 = by1; }
-        }
         if (lane == 0) { rs_finish(r, acc, r.n_eff, step); info[rev ? n_polys + i : i] = r; }
     }
+}
+template <class Src, bool CHAIN>
+__global__ __launch_bounds__(64) void k_cumlen_long2(Src src, int64_t n_polys, double step, float* __restrict__ cum, int64_t rev_off, RsInfo* __restrict__ info, const unsigned* __restrict__ ord,
+                                                     int dir0, const float* __restrict__ seg) {
+    cumlen_long_wave<Src, CHAIN>(src, n_polys, step, cum, rev_off, info, ord, ((blockIdx.y + (unsigned)dir0) & 1u) != 0, seg, blockIdx.x, gridDim.x, threadIdx.x);
+}
+// prefetch08: float32 length of EVERY segment of the long polylines (seg[off[i] + k] = |P(k + 1) - P(k)|, k < len(i) - 1) and the bounding box of their open
+// views (points [0, bb[i].n); bb[i] holds the first point's box on entry: k_poly_features), fully parallel: a wave takes 64 windows of 64 consecutive points
+// of the FLAT point list, advancing by 63, so the far end of a lane's segment is the point in the next lane and every lane's cursor stays on consecutive
+// points of (mostly) one polyline.  Both readings' cumulative lengths then run side by side from these lengths (one launch) instead of
+// the reversed reading behind the forward one, and so do the perimeter leaves (k_perim_leaves_seg).
+template <class Src>
+__global__ __launch_bounds__(256) void k_seglen(Src src, int64_t n_polys, int64_t total, float* __restrict__ seg, PolyFeat* __restrict__ bb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (63 * 64);
+    if (base >= total) return;                                 // (the whole wave)
+    int64_t g = base + lane;
+    int64_t i = 0;
+    { const int64_t gg = g < total ? g : total - 1; int64_t hi = n_polys - 1;        // polyline of the lane's first point: the last i with off[i] <= g
+      while (i < hi) { const int64_t mid = (i + hi + 1) >> 1; if (src.off[mid] <= gg) i = mid; else hi = mid - 1; } }
+    int64_t o0 = src.off[i], o1 = src.off[i + 1];
+    auto cu = src.cur(i);
+    bool is_long = o1 - o0 > ORIP_LONG_CUM;
+    int64_t vn = is_long ? bb[i].n : 0; if (vn <= ORIP_LONG_POLY) vn = 0;             // box wanted for points [0, vn) of this polyline
+    int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff; bool has = false;
+    for (int t = 0; t < 64 && base + 63 * t < total; t++, g += 63) {
+        const bool valid = g < total;
+        if (valid && g >= o1) {                                // the lane enters another polyline (rare: the long ones hold thousands of points)
+            if (has) { atomicMin(&bb[i].x0, bx0); atomicMax(&bb[i].x1, bx1); atomicMin(&bb[i].y0, by0); atomicMax(&bb[i].y1, by1); }
+            bx0 = by0 = 0x7fffffff; bx1 = by1 = -0x7fffffff; has = false;
+            do { i++; o0 = o1; o1 = src.off[i + 1]; } while (g >= o1);
+            cu = src.cur(i); is_long = o1 - o0 > ORIP_LONG_CUM;
+            vn = is_long ? bb[i].n : 0; if (vn <= ORIP_LONG_POLY) vn = 0;
+        }
+        const bool on = valid && is_long;
+        int2 p = make_int2(0, 0);
+        if (on) p = cu.at(g - o0);
+        const int2 q = lane_succ(p, make_int2(0, 0), lane);
+        if (on && lane < 63) {
+            if (g + 1 < o1) { float dx = (float)q.x - (float)p.x, dy = (float)q.y - (float)p.y; float qx = dx * dx, qy = dy * dy; seg[g] = sqrtf(qx + qy); }     // seg_len_f32
+            if (g - o0 < vn) { bx0 = min(bx0, p.x); bx1 = max(bx1, p.x); by0 = min(by0, p.y); by1 = max(by1, p.y); has = true; }
+        }
+    }
+    if (__all(i == __shfl(i, 0, 64))) {                        // the usual case: one polyline under the whole wave at the end
+        for (int o = 32; o > 0; o >>= 1) { bx0 = min(bx0, __shfl_xor(bx0, o, 64)); bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64)); }
+        if (lane == 0 && bx0 <= bx1) { atomicMin(&bb[i].x0, bx0); atomicMax(&bb[i].x1, bx1); atomicMin(&bb[i].y0, by0); atomicMax(&bb[i].y1, by1); }
+    } else if (has) { atomicMin(&bb[i].x0, bx0); atomicMax(&bb[i].x1, bx1); atomicMin(&bb[i].y0, by0); atomicMax(&bb[i].y1, by1); }
 }
 // any_out: set when a sampled polyline reaches beyond the canvas (its samples lie inside the box of its points): only then can a sample be
 // off-canvas, and only then does "the previous in-canvas sample" (k_capprev) differ from "the previous sample"
@@ -1502,27 +1538,39 @@ static int prefetch08(orip_ctx* c, const orip_params08& P, DPolys& S, const Poly
         VSrc sS; ORIP_TRY(vsrc_of(c, S, sS));
         // per-polyline fields first (open view, end points; bounding box and perimeters of the short ones): one thread per polyline
         hipLaunchKernelGGL(k_poly_features<VSrc>, dim3(cdiv(n, 128)), dim3(128), 0, LN(c).stream, sS, n, 1 | 16 | 32, ff, per_rev);
-        // A2 (the long polylines): cumulative lengths of both readings, longest first.  The forward reading fetches the points (once each) and leaves
-        // every segment's float32 length in F.seg and the open view's bounding box in ff; the reversed reading and the perimeter sums (A0 / A1,
-        // forwards and backwards) then read 4 bytes per segment instead of turning (polyline, index) into a point again.
+        // A2 (the long polylines): cumulative lengths of both readings, longest first.  k_seglen fetches the points (once each) and leaves every segment's
+        // float32 length in F.seg and the open view's bounding box in ff; both readings and the perimeter sums (A0 / A1, forwards and backwards) then
+        // read 4 bytes per segment instead of turning (polyline, index) into a point again.
         unsigned* kin = F.ord.as<unsigned>(); unsigned* kout = kin + n; unsigned* vin = kout + n; unsigned* ordl = vin + n;
         float* seg = F.seg.as<float>();
         hipLaunchKernelGGL(k_len_keys, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, S.off.as<int64_t>(), n, kin, vin);
         ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, kout, vin, ordl, (size_t)n, 0, 32, true)));
+        // (the sort borrows the lane's scan / sort scratch: the main stream, which sits in the greedy chain for milliseconds yet, takes it back behind this point)
+        HIPC(c, hipEventRecord(LN(c).ev4, LN(c).stream));
+        HIPC(c, hipStreamWaitEvent(LN(c).stream2 /* the main stream while the swap lives */, LN(c).ev4, 0));
+        // What stage 08 asks for first (split_small: boxes and perimeters) goes first and gets an event of its own (ev4); the cumulative lengths, which A2 picks
+        // up a dozen launches and a host read later, follow (ev3).
+        if (total > ORIP_LONG_CUM) {
+            { ProfScope ps(c, "k_seglen"); hipLaunchKernelGGL(k_seglen<VSrc>, dim3((unsigned)cdiv(total, 4 * 63 * 64)), dim3(256), 0, LN(c).stream, sS, n, total, seg, ff); }
+            if (total > ORIP_LONG_POLY) { ProfScope ps(c, "k_poly_features_long");
+                const size_t nleaf = (size_t)(total >> 6) + 2 * (size_t)n + 8;
+                HIPC(c, LN(c).vtmp[11].ensure(nleaf * sizeof(float) * 2 + 64));
+                float* leafbuf = LN(c).vtmp[11].as<float>(); float* leafbuf_rev = leafbuf + nleaf;
+                hipLaunchKernelGGL(k_perim_leaves_seg, dim3((unsigned)cdiv((int64_t)nleaf * 8, 256)), dim3(256), 0, LN(c).stream, sS.off, n, ff, seg, leafbuf, leafbuf_rev, (int64_t)nleaf);
+                hipLaunchKernelGGL((k_poly_features_long<VSrc, true>), dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, LN(c).stream, sS, n, 1 | 16 | 32 | 64, ff, leafbuf, ordl, per_rev, leafbuf_rev, seg); }
+        }
+        HIPC(c, hipEventRecord(LN(c).ev4, LN(c).stream));
         { ProfScope ps(c, "k_cumlen"); hipLaunchKernelGGL(k_cumlen2<VSrc>, dim3(cdiv(2 * n, 128)), dim3(128), 0, LN(c).stream, sS, feat07, n, step, cum, total, inf); }
-        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 1);
-            for (int dir = 0; dir < 2; dir++) {          // forward, then (reading what forward stored) reversed
+        if (total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); const dim3 grid((unsigned)std::min<int64_t>(n, 8192), 2);       // both readings side by side
 #ifdef ORIP_VARIANTS
-                if (ORIP_VARIANT("ORIP_CUM_CHAIN")) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
-                else
+            if (ORIP_VARIANT("ORIP_CUM_CHAIN")) hipLaunchKernelGGL((k_cumlen_long2<VSrc, true>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, 0, (const float*)seg);
+            else
 #endif
-                hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, dir, seg, ff);
-            } }
-        ORIP_TRY(vfeatures_long(c, sS, n, total, 1 | 16 | 32, ff, per_rev, seg));
+            hipLaunchKernelGGL((k_cumlen_long2<VSrc, false>), grid, dim3(64), 0, LN(c).stream, sS, n, step, cum, total, inf, ordl, 0, (const float*)seg); }
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventRecord(LN(c).ev3, LN(c).stream));
     }
-    HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev3, 0));      // the main stream (behind the greedy kernel) goes on when both are done
+    F.pending = true;             // nobody has waited yet: split_small (ev4), A2 (ev3), or the next call on the lane (orip_pf08_drain)
     F.valid = true; F.tag = g_pf_tag.fetch_add(1); F.n = n; F.tot_f = total; F.step = step; F.src_off = S.off.as<int64_t>();
     return 0;
 }
@@ -1545,10 +1593,11 @@ int split_small(orip_ctx* c, DPolys& src, const orip_params08& P, DPolys& kept, 
     HIPC(c, LN(c).vtmp[10].ensure((size_t)n * sizeof(PolyFeat) + 64));
     PolyFeat* sfeat = LN(c).vtmp[10].as<PolyFeat>();
     if (is_coded(src) && P.tap_max_v > 64) ORIP_TRY(orip_polys_materialize(c, src));      // the walk-coded tap test copies <= 64 vertices (default tap_max_vertices: 50)
-    const LaneRes::Prefetch08& F = LN(c).pf08;
-    if (kept_feat && is_coded(src) && src.pf_tag && F.valid && F.tag == src.pf_tag && !src.vident)        // computed under stage 07's greedy, per walk and direction
+    LaneRes::Prefetch08& F = LN(c).pf08;
+    if (kept_feat && is_coded(src) && src.pf_tag && F.valid && F.tag == src.pf_tag && !src.vident) {      // computed under stage 07's greedy, per walk and direction
+        if (F.pending) HIPC(c, hipStreamWaitEvent(LN(c).stream, LN(c).ev4, 0));
         hipLaunchKernelGGL(k_pf_pick_feat, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, src.vview.as<VView>(), n, F.feat.as<PolyFeat>(), reinterpret_cast<const float*>(F.feat.as<PolyFeat>() + F.n), sfeat);
-    else ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat));
+    } else { HIPC(c, orip_pf08_drain(c)); ORIP_TRY(vfeatures(c, src, kept_feat ? (1 | 16) : 0, sfeat)); }      // (the prefetch shares vfeatures' scratch)
     { ProfScope ps(c, "k_split_small08"); ORIP_WITH_SRC(c, src, sv, { hipLaunchKernelGGL(k_split_small08<decltype(sv)>, dim3(cdiv(n + 1, 128)), dim3(128), 0, LN(c).stream, sv, n, P, sfeat, is_tap, is_keep, tap_xy, kd); }); }
     ORIP_TRY(vscan_excl<unsigned>(c, is_tap, tap_scan, (size_t)n + 1));
     ORIP_TRY(vscan_excl<unsigned>(c, is_keep, keep_scan, (size_t)n + 1));
@@ -1586,7 +1635,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
     if (!prm || layer < 0 || layer >= ORIP_MAX_LAYERS) ORIP_FAIL(c, "bad arguments");
     const orip_params08 P = *prm;
     const int W = P.W, H = P.H;
-    ORIP_LANE(c, layer + 1);
+    ORIP_LANE_NODRAIN(c, layer + 1);       // stage 08 waits for the parts of its prefetch where it picks them up (split_small, A2)
     if (W <= 0 || H <= 0 || W > 16383 || H > 16383) ORIP_FAIL(c, "canvas %dx%d out of range", W, H);
     if (!(P.sample_step * 2.0 < P.max_jump)) ORIP_FAIL(c, "dedup_sample_step must be < max_join_jump_px / 2 (stage-A segments are assumed jump-free)");
     DPolys& S = c->polys[ORIP_SLOT_SORTED][layer]; DPolys& OUT = c->polys[ORIP_SLOT_LINES_INTRA][layer]; DTaps& TOUT = c->taps[ORIP_TAPS_INTRA][layer];
@@ -1626,6 +1675,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         const double step = std::max(1.0, P.sample_step);
         const LaneRes::Prefetch08& F = LN(c).pf08;
         const bool picked = is_coded(kept0.p) && kept0.p.pf_tag && F.valid && F.tag == kept0.p.pf_tag && F.step == step && !kept0.p.vident;
+        HIPC(c, orip_pf08_drain(c));          // the cumulative lengths of the prefetch (ev3), if nobody has waited for them yet
         HIPC(c, LN(c).vtmp[1].ensure((picked ? 0 : (size_t)kept0.p.total * 4) + (size_t)(nk + 1) * 8 + 128));
         int64_t* cumoff = LN(c).vtmp[1].as<int64_t>(); float* cum = reinterpret_cast<float*>(cumoff + (nk + 2));
         if (picked) {       // cumulative lengths and sample counts were taken under stage 07's greedy, per walk and direction: pick this list's
@@ -1637,7 +1687,7 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         if (kept0.p.total > ORIP_LONG_CUM) { ProfScope ps(c, "k_cumlen_long"); ORIP_WITH_SRC(c, kept0.p, sv, {
                 bool chain = false;
                 ORIP_CUM_CHAIN_LAUNCH(decltype(sv))
-                if (!chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (float*)nullptr, (PolyFeat*)nullptr); }); }
+                if (!chain) hipLaunchKernelGGL((k_cumlen_long2<decltype(sv), false>), dim3((unsigned)std::min<int64_t>(nk, 8192), 1), dim3(64), 0, LN(c).stream, sv, nk, step, cum, (int64_t)0, info, ord, 0, (const float*)nullptr); }); }
         }
         tick("cumlen");
         HIPC(c, hipMemsetAsync(sbase + nk + 1, 0, 4, LN(c).stream));

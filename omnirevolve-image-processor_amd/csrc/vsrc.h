@@ -44,8 +44,8 @@ struct VSrc {
             if (t <= w.n_own) return g.own[w.own_off + t];
             const unsigned u = t - w.n_own - 1u;
             if (u - pc_u0 >= pc_n) {                           // (unsigned: also u < pc_u0) another piece: the last one that starts at or before u
-                unsigned j = w.n_piece - 1u;
-                while (j > 0u && g.piece[w.piece_off + j].u0 > u) j--;
+                unsigned j = 0u, hi = w.n_piece - 1u;                   // (a walk may hold thousands of pieces, and a fresh cursor starts here)
+                while (j < hi) { const unsigned mid = (j + hi + 1u) >> 1; if (g.piece[w.piece_off + mid].u0 <= u) j = mid; else hi = mid - 1u; }
                 const VPiece q = g.piece[w.piece_off + j];
                 pc_u0 = q.u0; pc_ent = q.ent; pc_lam = q.lam; pc_magic = q.magic;
                 pc_n = (j + 1u < w.n_piece ? g.piece[w.piece_off + j + 1u].u0 : 0xffffffffu) - q.u0;
