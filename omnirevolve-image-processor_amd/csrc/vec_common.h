@@ -11,8 +11,9 @@ namespace {   // every TU that includes this header gets its own copy of the ker
 // ---- rocPRIM wrappers (temporary storage in ctx->tmpF) ----
 // exclusive prefix sums of up to 32 768 integers by ONE workgroup (thread t owns the items [t * per, (t + 1) * per)): the lists of this path are a few
 // thousand polylines long, and rocPRIM's scan is two dispatches (look-back state, scan) at ~50 us each on a queue that shares the card.  in == out is fine.
+// (256 threads: a 1024-thread workgroup waits for a CU with sixteen free wave slots, which costs ~0.5 ms on a card the other layers keep full.)
 template <class T>
-__global__ __launch_bounds__(1024) void k_scan_small(const T* in, T* out, unsigned n, unsigned per) {
+__global__ __launch_bounds__(256) void k_scan_small(const T* in, T* out, unsigned n, unsigned per) {
     __shared__ T wsum[16];
     const unsigned tid = threadIdx.x, lo = tid * per, hi = min(n, lo + per);
     T mine = 0;
@@ -31,7 +32,7 @@ template <class T>
 static int vscan_excl(orip_ctx* c, const T* in, T* out, size_t n) {
     if (n == 0) return 0;
     if (n <= 32768) {
-        hipLaunchKernelGGL(k_scan_small<T>, dim3(1), dim3(1024), 0, LN(c).stream, in, out, (unsigned)n, (unsigned)cdiv((int64_t)n, 1024));
+        hipLaunchKernelGGL(k_scan_small<T>, dim3(1), dim3(256), 0, LN(c).stream, in, out, (unsigned)n, (unsigned)cdiv((int64_t)n, 256));
         HIPC(c, hipGetLastError());
         return 0;
     }
@@ -826,13 +827,14 @@ __global__ __launch_bounds__(256) void k_desc_from_order(const int64_t* __restri
 }
 
 // argmax with first-max tie-break over a float / double field of PolyFeat (seed of the greedy orders); tiny: single block
-__global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict__ f, int n, int use_arc, int* __restrict__ out, const NNEnds* __restrict__ e = nullptr) {
-    __shared__ double bv[1024]; __shared__ int bi[1024];
+// (one 256-thread block: a 1024-thread block waits for a CU with sixteen free wave slots -- half a millisecond next to the other layers' work, in front of the greedy chain)
+__global__ __launch_bounds__(256) void k_argmax_feat(const PolyFeat* __restrict__ f, int n, int use_arc, int* __restrict__ out, const NNEnds* __restrict__ e = nullptr) {
+    __shared__ double bv[256]; __shared__ int bi[256];
     __shared__ int bad_s;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
     double v = -1.0; int idx = 0x7fffffff; int bad = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = threadIdx.x; i < n; i += 256) {
         double x = use_arc ? f[i].arc : (double)f[i].per; if (x > v) { v = x; idx = i; }
         if (e) {      // the coordinate-range flags of the greedy kernels in the same pass (k_ends_fit16's: bit 0 beyond int16, bit 1 beyond 15 bits): out[1]
             const NNEnds q = e[i];
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_argmax_feat(const PolyFeat* __restrict
     if (bad) atomicOr(&bad_s, bad);
     bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             double o = bv[threadIdx.x + s]; int oi = bi[threadIdx.x + s];
             if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
@@ -1420,7 +1422,7 @@ static int vreorder(orip_ctx* c, DPolys& src, DPolys& dst, int kind, ReorderHook
     } else ORIP_TRY(vfeatures(c, src, what, feat));
     ORIP_WITH_SRC(c, src, ps, { hipLaunchKernelGGL(k_ends_from_feat<decltype(ps)>, dim3(cdiv(n, 256)), dim3(256), 0, LN(c).stream, feat, n, kind == 7 ? 1 : 0, ps, ends); });
     int* d_seed = LN(c).flags.as<int>() + 32;
-    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(1024), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed, ends);      // seed and coordinate-range flags in one pass
+    hipLaunchKernelGGL(k_argmax_feat, dim3(1), dim3(256), 0, LN(c).stream, feat, (int)n, kind == 8 ? 0 : 1, d_seed, ends);      // seed and coordinate-range flags in one pass
     const size_t lds = (size_t)n * 9 + 16;
     // grid side: as fine as LDS allows (cells are powers of two, so twice the side is four times fewer candidates per window),
     // but not many more cells than polylines
