@@ -130,6 +130,8 @@ def main():
             dist.barrier()
         dev.sync()
 
+    rank_times = {}             # N > 1: this rank's stage times of the LAST step (orip.parallel.run_path_sharded)
+
     def step(fetch=False):
         if args.upto == 3:
             centers, _ = dev.kmeans_fit(S.subsample_indices(H * W), K)
@@ -137,7 +139,7 @@ def main():
             S._detect_edges_resident(dev, cfg)
             dev.sync()
             return 0
-        return P.run_path_sharded(dev, cfg, H, W, rank, world, coll_device, fetch_lines=fetch, comm=comm)
+        return P.run_path_sharded(dev, cfg, H, W, rank, world, coll_device, fetch_lines=fetch, comm=comm, timings=rank_times)
 
     for _ in range(args.warmup):
         step(fetch=True)
@@ -157,6 +159,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    per_rank = None
+    if dist is not None and args.upto == 12:      # where each rank's time went in the last timed step (host clock, ms from the step's start)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(rank_times))
+        per_rank = gathered
     elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed / max(1, args.steps) * 1e3
     value = (H * W / 1e6) * args.steps / elapsed
@@ -326,6 +333,8 @@ def main():
                        "ops_last_step_rank0": int(n_ops), "exchange": (comm.kind if comm is not None else "none")},
             "inclusive": inclusive, "pipelined": pipelined, "roofline": roofline, "kernel_groups": groups_out, "c2": c2, "cpu_baseline": cpu,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank          # host-side stage times of every rank in the last timed step (orip.parallel.run_path_sharded)
         if world > 1 and n_vis < world:
             out["note"] = f"{world} ranks shared {n_vis} visible GPU(s) (gloo rehearsal): NOT a multi-GPU scaling point"
         print(json.dumps(out), flush=True)

@@ -175,7 +175,7 @@ def comm_of(dev, rank: int, world: int, coll_device=None):
     return comm
 
 
-def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None, fetch_lines: bool = False, comm=None):
+def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_device=None, fetch_lines: bool = False, comm=None, timings: dict | None = None):
     """One step of stages 02 -> 12 with the image already resident on `dev` (orip.device.Device).  The op rows of every owned layer
     come back to the host; fetch_lines: so do the points of its lines (what ops.pkl holds, 12:206-208).
     world > 1: rank r ends with the lists and ops of its layers owned_layers(K, r, world) under local indices 0..len-1.
@@ -183,9 +183,17 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
     world > 1: every rank pipelines its own layers (04 -> 08, one lane each).  Stage 10 is replicated and streamed: the
     layers are visited dark -> light; the owner of the next layer waits for its pipeline, broadcasts the layer's
     (lines_intra, taps_intra) and everybody cuts it against the shared raster.  So, as on one GPU, stage 10 of the early
-    layers runs underneath the 04-08 work of the heavy ones, and a layer's stage 12 starts as soon as it has left stage 10."""
+    layers runs underneath the 04-08 work of the heavy ones, and a layer's stage 12 starts as soon as it has left stage 10.
+
+    timings (world > 1): filled with this rank's host-side stage times of the step, in ms from its start -- `raster` (stage 02 returned),
+    `front_ready` {global layer: its 04 -> 08 pipeline done}, `own_wait` (waiting for own layers in stage 10's visit order),
+    `exchange` (inside the broadcasts: the wait for the other owners' layers plus the transfer), `cross` (stage 10 calls), `total`."""
+    import time as _time
     from . import lib as _l
     from . import stages as S
+
+    t_start = _time.perf_counter()
+    ms_since = lambda: (_time.perf_counter() - t_start) * 1e3
 
     names = list(cfg.color_names)
     K = max(2, len(names))
@@ -209,13 +217,22 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
     if comm is None:
         comm = comm_of(dev, rank, world, coll_device)       # cached on the device: a second sharded step reuses it
     mine = owned_layers(K, rank, world)              # global layer ids; held under local indices 0..len(mine)-1
+    T = {"rank": rank, "layers": list(mine), "raster": round(ms_since(), 2), "front_ready": {}, "own_wait": 0.0, "exchange": 0.0, "cross": 0.0}
     ready, errors = {}, []
     if mine:
         dev.keep_layers(mine)
         S._detect_edges_resident(dev, cfg)
         dev.contours_prepare()
         order_local = [mine.index(g) for g in order if g in mine]
-        ready, errors = S._start_fronts(S.layer_front(dev, cfg, W, H, 8), range(len(mine)), order_local)
+        front = S.layer_front(dev, cfg, W, H, 8)
+
+        def timed_front(i):
+            try:
+                front(i)
+            finally:
+                T["front_ready"][mine[i]] = round(ms_since(), 2)
+
+        ready, errors = S._start_fronts(timed_front, range(len(mine)), order_local)
     pool = S._get_pool()
     dev.dedup_cross_begin(S.params10(cfg))
     # Every list of an owned layer lives under its LOCAL index i (CONTOURS ... LINES_CROSS, taps, ops) and all per-layer calls of
@@ -230,19 +247,24 @@ def run_path_sharded(dev, cfg, H: int, W: int, rank: int, world: int, coll_devic
         owner = g % world
         if owner == rank:
             i = mine.index(g)
-            ready[i].wait()
+            t = ms_since(); ready[i].wait(); T["own_wait"] += ms_since() - t
             failed = bool(errors)
             if failed:                                  # the other ranks are waiting in the collective: never skip it, send an empty layer
                 dev.set_polys(_l.SLOT_LINES_INTRA, i, []); dev.set_taps(_l.TAPS_INTRA, i, [])
-            comm.bcast(owner, i, True)
+            t = ms_since(); comm.bcast(owner, i, True); T["exchange"] += ms_since() - t
             if failed:
                 continue
-            dev.dedup_cross_layer(i, src_layer=i, defer_reorder=True)      # tail(): plot_order reorders the lines first, on lane i + 1
+            t = ms_since(); dev.dedup_cross_layer(i, src_layer=i, defer_reorder=True); T["cross"] += ms_since() - t      # tail(): plot_order reorders the lines first, on lane i + 1
             tails.append(pool.submit(tail, i))
         else:
-            comm.bcast(owner, stage_slot, False)
-            dev.dedup_cross_layer(stage_slot, src_layer=stage_slot)
+            t = ms_since(); comm.bcast(owner, stage_slot, False); T["exchange"] += ms_since() - t
+            t = ms_since(); dev.dedup_cross_layer(stage_slot, src_layer=stage_slot); T["cross"] += ms_since() - t
     n_ops = sum(len(f.result()) for f in tails)
+    if timings is not None:
+        for k in ("own_wait", "exchange", "cross"):
+            T[k] = round(T[k], 2)
+        T["total"] = round(ms_since(), 2)
+        timings.clear(); timings.update(T)
     if errors:
         for e in ready.values():
             e.wait()

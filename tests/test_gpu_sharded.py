@@ -60,8 +60,13 @@ def _worker(rank, world, port, q, cold=False):
             dev.set_image(img)
             P.run_path_sharded(dev, cfg, H, W, rank, world, "cpu")
             dev.set_image(img)
-            P.run_path_sharded(dev, cfg, H, W, rank, world, "cpu")     # a second sharded step without `comm`: the communicator is reused, not rebuilt
+            times = {}
+            P.run_path_sharded(dev, cfg, H, W, rank, world, "cpu", timings=times)     # a second sharded step without `comm`: the communicator is reused, not rebuilt
             assert dev._comm is not None
+            # the per-rank stage times bench.py prints for N > 1: this rank's layers, each front's finish time, and the parts of the stage-10 visit
+            assert times["rank"] == rank and times["layers"] == mine and sorted(times["front_ready"]) == sorted(mine)
+            assert 0 < times["raster"] <= times["total"] and all(times["raster"] <= t <= times["total"] for t in times["front_ready"].values())
+            assert min(times["own_wait"], times["exchange"], times["cross"]) >= 0 and times["own_wait"] + times["exchange"] + times["cross"] <= times["total"]
             got = snapshot(mine)
         ok = True
         for g in mine:
