@@ -117,6 +117,13 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
 #undef ORIP_DPP_ADD
     return v;
 }
+__device__ __forceinline__ unsigned wave_incl_scan_max_u32(unsigned v) {                  // running maximum over the lanes, the same six DPP steps
+#define ORIP_DPP_MAX(ctrl, rowmask) { const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = t_ > v ? t_ : v; }
+    ORIP_DPP_MAX(0x111, 0xf) ORIP_DPP_MAX(0x112, 0xf) ORIP_DPP_MAX(0x114, 0xf) ORIP_DPP_MAX(0x118, 0xf)
+    ORIP_DPP_MAX(0x142, 0xa) ORIP_DPP_MAX(0x143, 0xc)
+#undef ORIP_DPP_MAX
+    return v;
+}
 __device__ __forceinline__ float cum_window(float dval, int lane, unsigned& E, unsigned& M) {
     const unsigned b = __float_as_uint(dval);
     const unsigned Ed = b >> 23, Md = Ed ? ((b & 0x7fffffu) | 0x800000u) : 0u;
@@ -585,16 +592,17 @@ __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__
             const unsigned s = j0 + (unsigned)lane; const bool valid = s < m && s < cb + C;
             unsigned hp = valid ? NPl[s & (C - 1u)] : 0u;
             hp = hp > head ? hp : head;
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)hp, o, 64); if (lane >= o && t > hp) hp = t; }      // heads never move back: running maximum
-            unsigned prevh = (unsigned)__shfl_up((int)hp, 1, 64); if (lane == 0) prevh = head;
+            hp = wave_incl_scan_max_u32(hp);                                               // heads never move back: running maximum (DPP steps: a ds_bpermute
+                                                                                           // round trip per step was a quarter of the round)
+            unsigned prevh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hp, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); if (lane == 0) prevh = head;
             const unsigned np = hp - prevh;
-            unsigned inc = valid ? 1u + np : 0u, off = inc;
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)off, o, 64); if (lane >= o) off += t; }
+            const unsigned inc = valid ? 1u + np : 0u;
+            unsigned off = wave_incl_scan_u32(inc);
             const unsigned long long fitm = __ballot(valid && off <= 64u);                 // (off is increasing over the valid lanes: a prefix)
             const int m_fit = __popcll(fitm);
             if (m_fit == 0) { plain(j0); j0++; continue; }                                 // a sample with more than 63 pops: the plain loop
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)off, m_fit - 1);
             off -= inc;                                                                    // exclusive
-            const unsigned total = (unsigned)__shfl((int)(off + inc), m_fit - 1, 64);
             if (lane < m_fit) {
                 ops[off] = s > prevh ? dist(s) : 0.0;                                      // the push adds nothing to an empty queue
                 for (unsigned t = 0; t < np; t++) ops[off + 1u + t] = -dist(prevh + 1u + t);
@@ -616,8 +624,8 @@ __global__ __launch_bounds__(64) void k_tail_replay(const unsigned* __restrict__
             const int ncommit = badm ? __ffsll((long long)badm) - 1 : m_fit;
             if (lane < ncommit) NP[s] = hp;
             if (ncommit > 0) {
-                head = (unsigned)__shfl((int)hp, ncommit - 1, 64);
-                const unsigned last_op = (unsigned)__shfl((int)(off + np), ncommit - 1, 64);
+                head = (unsigned)__builtin_amdgcn_readlane((int)hp, ncommit - 1);
+                const unsigned last_op = (unsigned)__builtin_amdgcn_readlane((int)(off + np), ncommit - 1);
                 racc = rr[last_op];
             }
             __syncthreads();
