@@ -1070,16 +1070,9 @@ __global__ __launch_bounds__(256) void k_bits_to_mask(const unsigned long long* 
         if (x < W) m[(size_t)y * W + x] = ((b >> lane) & 1ULL) ? 255 : 0;
     }
 }
-__global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __restrict__ s, unsigned long long* __restrict__ d, int H, int Ww, int sub, int* __restrict__ changed) {
-    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (wi >= (size_t)H * Ww) return;
-    const int y = (int)(wi / Ww), xw = (int)(wi % Ww);
-    const unsigned long long M = s[wi];
-    if (!M) { d[wi] = 0; return; }
-    auto W64 = [&](int yy, int xx) -> unsigned long long { return (yy < 0 || yy >= H || xx < 0 || xx >= Ww) ? 0ULL : s[(size_t)yy * Ww + xx]; };
-    const unsigned long long U = W64(y - 1, xw), UL = W64(y - 1, xw - 1), UR = W64(y - 1, xw + 1);
-    const unsigned long long ML = W64(y, xw - 1), MR = W64(y, xw + 1);
-    const unsigned long long D = W64(y + 1, xw), DL = W64(y + 1, xw - 1), DR = W64(y + 1, xw + 1);
+// one Zhang-Suen sub-iteration on a 64-pixel word, bit-sliced: M = the word, the other eight = its neighbour words; returns the pixels it deletes
+__device__ __forceinline__ unsigned long long zs_word_del(unsigned long long M, unsigned long long U, unsigned long long UL, unsigned long long UR, unsigned long long ML,
+                                                          unsigned long long MR, unsigned long long D, unsigned long long DL, unsigned long long DR, int sub) {
     // neighbour planes in the reference's numbering: P2 = north, then clockwise
     const unsigned long long P2 = U, P3 = (U >> 1) | (UR << 63), P4 = (M >> 1) | (MR << 63), P5 = (D >> 1) | (DR << 63);
     const unsigned long long P6 = D, P7 = (D << 1) | (DL >> 63), P8 = (M << 1) | (ML >> 63), P9 = (U << 1) | (UL >> 63);
@@ -1098,9 +1091,68 @@ __global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __res
     TR(P2, P3); TR(P3, P4); TR(P4, P5); TR(P5, P6); TR(P6, P7); TR(P7, P8); TR(P8, P9); TR(P9, P2);
     const unsigned long long Aok = one & ~two;
     const unsigned long long cnd = sub == 0 ? (~(P2 & P4 & P6) & ~(P4 & P6 & P8)) : (~(P2 & P4 & P8) & ~(P2 & P6 & P8));
-    const unsigned long long del = M & Aok & Bok & cnd;
+    return M & Aok & Bok & cnd;
+}
+__global__ __launch_bounds__(256) void k_zs_bits(const unsigned long long* __restrict__ s, unsigned long long* __restrict__ d, int H, int Ww, int sub, int* __restrict__ changed) {
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= (size_t)H * Ww) return;
+    const int y = (int)(wi / Ww), xw = (int)(wi % Ww);
+    const unsigned long long M = s[wi];
+    if (!M) { d[wi] = 0; return; }
+    auto W64 = [&](int yy, int xx) -> unsigned long long { return (yy < 0 || yy >= H || xx < 0 || xx >= Ww) ? 0ULL : s[(size_t)yy * Ww + xx]; };
+    const unsigned long long del = zs_word_del(M, W64(y - 1, xw), W64(y - 1, xw - 1), W64(y - 1, xw + 1), W64(y, xw - 1), W64(y, xw + 1), W64(y + 1, xw), W64(y + 1, xw - 1), W64(y + 1, xw + 1), sub);
     if (del) *changed = 1;
     d[wi] = M & ~del;
+}
+// `iters` whole iterations (two sub-iterations each) in ONE launch: a block keeps a tile of 64 rows x 2 words plus a halo of ZS_HALO rows / one word on
+// every side in LDS and runs the sub-iterations there.  A sub-iteration reads the 3x3 neighbourhood, so after t of them the tile is exact everywhere at
+// least t pixels inside the staged region: with iters <= ZS_HALO / 2 the core is exact after all of them, whatever the neighbouring tiles do meanwhile
+// (they read the same source plane s; the result goes to d).  changed[b] is set when iteration b deletes a pixel of some core.  Twelve iterations were
+// 24 dispatches of ~30 us on the layer's chain; most tiles of a canvas of thin lines are empty and leave after the staging.
+#define ZS_HALO 24
+#define ZS_TR 64
+#define ZS_ROWS (ZS_TR + 2 * ZS_HALO)
+__global__ __launch_bounds__(256) void k_zs_tile(const unsigned long long* __restrict__ s, unsigned long long* __restrict__ d, int H, int Ww, int iters, int* __restrict__ changed) {
+    __shared__ unsigned long long T[2][ZS_ROWS][4];
+    __shared__ int any_s;
+    const int tid = threadIdx.x;
+    const int y0 = blockIdx.y * ZS_TR - ZS_HALO, x0 = blockIdx.x * 2 - 1;          // first staged row / word
+    if (tid == 0) any_s = 0;
+    __syncthreads();
+    int any = 0;
+    for (int i = tid; i < ZS_ROWS * 4; i += 256) {
+        const int r = i >> 2, wx = i & 3, y = y0 + r, xw = x0 + wx;
+        const unsigned long long v = (y < 0 || y >= H || xw < 0 || xw >= Ww) ? 0ULL : s[(size_t)y * Ww + xw];
+        T[0][r][wx] = v; any |= v != 0;
+    }
+    if (any) any_s = 1;
+    __syncthreads();
+    const bool empty = !any_s;
+    int cur = 0;
+    if (!empty) {
+        for (int t = 0; t < 2 * iters; t++) {
+            int del_core = 0;
+            for (int i = tid; i < ZS_ROWS * 4; i += 256) {
+                const int r = i >> 2, wx = i & 3;
+                const unsigned long long M = T[cur][r][wx];
+                unsigned long long out = 0;
+                if (M) {
+                    auto G = [&](int rr, int ww) -> unsigned long long { return (rr < 0 || rr >= ZS_ROWS || ww < 0 || ww > 3) ? 0ULL : T[cur][rr][ww]; };
+                    const unsigned long long del = zs_word_del(M, G(r - 1, wx), G(r - 1, wx - 1), G(r - 1, wx + 1), G(r, wx - 1), G(r, wx + 1), G(r + 1, wx), G(r + 1, wx - 1), G(r + 1, wx + 1), t & 1);
+                    out = M & ~del;
+                    if (del && r >= ZS_HALO && r < ZS_HALO + ZS_TR && (wx == 1 || wx == 2)) del_core = 1;
+                }
+                T[cur ^ 1][r][wx] = out;
+            }
+            if (del_core) changed[t >> 1] = 1;
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < ZS_TR * 2; i += 256) {
+        const int r = ZS_HALO + (i >> 1), wx = 1 + (i & 1), y = y0 + r, xw = x0 + wx;
+        if (y < H && xw < Ww) d[(size_t)y * Ww + xw] = empty ? 0ULL : T[cur][r][wx];
+    }
 }
 // plain (linear id) union-find CCL on the padded raster
 #ifdef ORIP_VARIANTS      // replaced variant (ORIP_THIN_BYTES): variants build only (make variants)
@@ -1879,6 +1931,11 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
             for (int it = 0; it < 48; ) {
                 const int nb = it == 0 ? 12 : 4;
                 HIPC(c, hipMemsetAsync(d_chg, 0, 48, LN(c).stream));
+                if (!getenv("ORIP_ZS_LAUNCHES")) {          // the whole batch in one launch, tile by tile in LDS (ORIP_ZS_LAUNCHES=1: one launch per sub-iteration, as before)
+                    ProfScope ps(c, "k_zs_sub");
+                    hipLaunchKernelGGL(k_zs_tile, dim3((unsigned)cdiv(Wwp, 2), (unsigned)cdiv(Hp, ZS_TR)), blk, 0, LN(c).stream, bA, bB, Hp, Wwp, nb, d_chg);
+                    std::swap(bA, bB);
+                } else
                 for (int b = 0; b < nb; b++) {
                     { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bA, bB, Hp, Wwp, 0, d_chg + b); }
                     { ProfScope ps(c, "k_zs_sub"); hipLaunchKernelGGL(k_zs_bits, gwd, blk, 0, LN(c).stream, bB, bA, Hp, Wwp, 1, d_chg + b); }
