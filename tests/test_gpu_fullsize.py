@@ -57,8 +57,8 @@ def test_schedules_and_kernel_variants_agree(setup, monkeypatch):
     digests = []
     # (ORIP_KMEANS_1WG, ORIP_THIN_BYTES, ORIP_CUM_CHAIN select replaced kernels that only the variants build carries -- `make -C csrc variants`,
     # ORIP_LIB_VARIANTS=1 -- and read as not set with the default library; the other switches force paths the default library falls back to)
-    for env in [{}, {"ORIP_SERIAL_LAYERS": "1"}, {"ORIP_KMEANS_1WG": "1", "ORIP_TAIL_SEQ": "1", "ORIP_NN_NOGRID": "1", "ORIP_PLOT_1WG": "1", "ORIP_TAPS_1WG": "1", "ORIP_MORPH_BYTES": "1", "ORIP_THIN_BYTES": "1", "ORIP_CCL_BYTES": "1", "ORIP_HASH_SORT": "1", "ORIP_NO_CHAINS": "1", "ORIP_NO_PREFETCH08": "1", "ORIP_CAPS_FULL": "1", "ORIP_CAPPREV_SCAN": "1", "ORIP_CUM_CHAIN": "1", "ORIP_NN_NOASM": "1", "ORIP_ARC_POINTS": "1"}]:
-        for k in ("ORIP_SERIAL_LAYERS", "ORIP_KMEANS_1WG", "ORIP_TAIL_SEQ", "ORIP_NN_NOGRID", "ORIP_PLOT_1WG", "ORIP_TAPS_1WG", "ORIP_MORPH_BYTES", "ORIP_THIN_BYTES", "ORIP_CCL_BYTES", "ORIP_HASH_SORT", "ORIP_NO_CHAINS", "ORIP_NO_PREFETCH08", "ORIP_CAPS_FULL", "ORIP_CAPPREV_SCAN", "ORIP_CUM_CHAIN", "ORIP_NN_NOASM", "ORIP_ARC_POINTS"):
+    for env in [{}, {"ORIP_SERIAL_LAYERS": "1"}, {"ORIP_KMEANS_1WG": "1", "ORIP_TAIL_SEQ": "1", "ORIP_NN_NOGRID": "1", "ORIP_PLOT_1WG": "1", "ORIP_TAPS_1WG": "1", "ORIP_MORPH_BYTES": "1", "ORIP_THIN_BYTES": "1", "ORIP_CCL_BYTES": "1", "ORIP_HASH_SORT": "1", "ORIP_NO_CHAINS": "1", "ORIP_NO_PREFETCH08": "1", "ORIP_CAPS_FULL": "1", "ORIP_CAPPREV_SCAN": "1", "ORIP_CUM_CHAIN": "1", "ORIP_NN_NOASM": "1", "ORIP_ARC_POINTS": "1", "ORIP_ZS_LAUNCHES": "1"}]:
+        for k in ("ORIP_SERIAL_LAYERS", "ORIP_KMEANS_1WG", "ORIP_TAIL_SEQ", "ORIP_NN_NOGRID", "ORIP_PLOT_1WG", "ORIP_TAPS_1WG", "ORIP_MORPH_BYTES", "ORIP_THIN_BYTES", "ORIP_CCL_BYTES", "ORIP_HASH_SORT", "ORIP_NO_CHAINS", "ORIP_NO_PREFETCH08", "ORIP_CAPS_FULL", "ORIP_CAPPREV_SCAN", "ORIP_CUM_CHAIN", "ORIP_NN_NOASM", "ORIP_ARC_POINTS", "ORIP_ZS_LAUNCHES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
