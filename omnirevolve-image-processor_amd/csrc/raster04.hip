@@ -450,6 +450,7 @@ extern "C" int orip_contours_reserve(orip_ctx* c, int K) {
     return 0;
 }
 
+static int trace_launch(orip_ctx* c, Prep04& R, int layer, unsigned F);
 extern "C" int orip_contours_prepare(orip_ctx* c) {
     orip_enter(c);
     if (!c->edges.p || c->K < 1) ORIP_FAIL(c, "no edges resident (run orip_detect_edges or orip_set_edges)");
@@ -628,6 +629,17 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     A.log_used = LN(c).vtmp[7].as<unsigned>();         // written by every component's trace
     HIPC(c, hipStreamSynchronize(LN(c).stream));
     R.ready = true;
+    // The layers' traces start right here, from the calling thread, each on its layer's lane: the walks head every layer's chain, and the hand-over to the
+    // layer threads (orip_contours_layer, which then only waits for its trace) costs 0.3-0.5 ms in which the card would sit idle.  A lane that another
+    // thread holds is left to its orip_contours_layer call (ORIP_TRACE_LATE=1: all of them, as before).
+    if (!getenv("ORIP_TRACE_LATE"))
+        for (int l = 0; l < R.K; l++) {
+            if (R.layer_first[l] == R.layer_first[l + 1]) continue;
+            LaneGuard g(c, l + 1);
+            if (!g.ok) continue;
+            HIPC(c, orip_pf08_drain(c));
+            ORIP_TRY(trace_launch(c, R, l, 64));
+        }
     return 0;
 }
 
@@ -760,7 +772,7 @@ int orip_contours_layer_impl(orip_ctx* c, int layer, bool sync) {
     if (layer < 0 || layer >= R->K) ORIP_FAIL(c, "bad layer %d (prepared for %d layers)", layer, R->K);
     if (R->M == 0 || R->layer_first[layer] == R->layer_first[layer + 1]) return 0;
     ORIP_LANE(c, layer + 1);
-    ORIP_TRY(trace_launch(c, *R, layer, 64));
+    if (!R->launched[layer]) ORIP_TRY(trace_launch(c, *R, layer, 64));      // (normally enqueued by orip_contours_prepare already)
     ORIP_TRY(trace_finish(c, *R, layer));
     if (sync) HIPC(c, hipStreamSynchronize(LN(c).stream));
     return 0;
@@ -776,7 +788,7 @@ extern "C" int orip_find_contours(orip_ctx* c) {
     Prep04& R = *static_cast<Prep04*>(c->prep04);
     if (R.M == 0) return 0;
     // every layer's trace is enqueued on its own stream first, so the long serial walks of all layers overlap
-    for (int l = 0; l < R.K; l++) if (R.layer_first[l] != R.layer_first[l + 1]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
+    for (int l = 0; l < R.K; l++) if (R.layer_first[l] != R.layer_first[l + 1] && !R.launched[l]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_launch(c, R, l, 64)); }
     for (int l = 0; l < R.K; l++) if (R.launched[l]) { ORIP_LANE(c, l + 1); ORIP_TRY(trace_finish(c, R, l)); HIPC(c, hipStreamSynchronize(LN(c).stream)); }
     return 0;
 }
