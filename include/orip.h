@@ -114,7 +114,9 @@ int orip_find_contours(orip_ctx* ctx);
 int orip_contours_reserve(orip_ctx* ctx, int K);
 
 /* The same work split for per-layer pipelines: prepare = the part batched over the layers (thinning 04:35-99, components, walk
- * schedule); contours_layer = the walks of one layer (04:101-211), callable for different layers from different host threads. */
+ * schedule); contours_layer = the walks of one layer (04:101-211), callable for different layers from different host threads.
+ * prepare also enqueues every layer's walk on that layer's stream before it returns, so contours_layer normally only completes a
+ * walk that is already running (a layer whose lane is held by another call at that moment is started by its contours_layer call). */
 int orip_contours_prepare(orip_ctx* ctx);
 int orip_contours_layer(orip_ctx* ctx, int layer);
 int orip_get_skeleton(orip_ctx* ctx, int layer, uint8_t* skel_out); /* thinning_zhangsuen output (04:35-99) */
