@@ -206,6 +206,19 @@ inline hipError_t orip_pf08_drain(orip_ctx* c) {           // the claimed lane's
 }
 inline LaneGuard::~LaneGuard() { if (ok) orip_tls_lane = prev; if (owner) c->lane_owner[lane].store(0); }
 
+#if defined(__HIPCC__)
+// one bit per pixel -> 0 / 255 bytes, 16 pixels (ONE 16-byte store) per thread: rows that are multiples of 64 wide (nw words per plane = H * W / 64),
+// blockIdx.z = plane.  Four bits become four bytes by a multiply that drops bit i at position 8 i (n * (1 + 2^7 + 2^14 + 2^21), no carries) and a mask.
+static __global__ __launch_bounds__(256) void k_bits_expand16(const unsigned long long* __restrict__ bits, uint8_t* __restrict__ dst, size_t nw) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nw * 4) return;
+    const unsigned long long w = bits[nw * blockIdx.z + (t >> 2)];
+    const unsigned n16 = (unsigned)(w >> ((t & 3) * 16)) & 0xffffu;
+    auto four = [](unsigned n4) { return (((n4 & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu; };
+    uint4 o; o.x = four(n16); o.y = four(n16 >> 4); o.z = four(n16 >> 8); o.w = four(n16 >> 12);
+    reinterpret_cast<uint4*>(dst + nw * 64 * blockIdx.z)[t] = o;
+}
+#endif
 // Time one kernel launch with HIP events on ctx->stream when profiling is enabled (bench.py roofline leg).
 struct ProfScope {
     orip_ctx* c; const char* name;

@@ -752,6 +752,29 @@ __global__ __launch_bounds__(256) void k_bits_pack(const u8* __restrict__ src, u
     for (int j = 0; j < n; j++) { const u8 v = row[x0 + j]; if (labels_mode ? (v == layer) : (v != 0)) b |= 1ULL << j; }
     bits[(size_t)H * Ww * layer + wi] = b;
 }
+// labels -> K bit planes in ONE pass over the label plane (rows that are multiples of 64 wide): a thread takes the 64 labels of a word as four 16-byte
+// loads and emits the word of every layer -- per layer and 4 labels an exact "byte equals l" test on the 32-bit word (zero-byte detection of w ^ l l l l) and a
+// multiply that gathers the four flag bits.  k_bits_pack read the plane once per layer, a byte per load and lane (0.25 ms at 4096^2 x 8 in front of the walks).
+__global__ __launch_bounds__(256) void k_bits_pack_labels(const u8* __restrict__ labels, unsigned long long* __restrict__ bits, int H, int W, int Ww, int K) {
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x, nw = (size_t)H * Ww;
+    if (wi >= nw) return;
+    const uint4* p = reinterpret_cast<const uint4*>(labels + wi * 64);          // W == 64 * Ww: word wi holds the pixels 64 wi .. 64 wi + 63 of the plane
+    uint32_t w[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint4 v = p[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    for (int l = 0; l < K; l++) {
+        const uint32_t rep = 0x01010101u * (uint32_t)l;
+        unsigned long long b = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t x = w[q] ^ rep;
+            const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);          // 0x80 in every byte of x that is zero, 0 elsewhere
+            const uint32_t nib = ((z >> 7) * 0x00204081u) >> 21 & 0xfu;                        // bits 0, 8, 16, 24 -> bits 0 .. 3
+            b |= (unsigned long long)nib << (4 * q);
+        }
+        bits[nw * l + wi] = b;
+    }
+}
 __global__ __launch_bounds__(256) void k_bits_unpack(const unsigned long long* __restrict__ bits, u8* __restrict__ dst, int H, int W, int Ww) {
     const int layer = blockIdx.z;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;                // four pixels per thread
@@ -830,6 +853,7 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
         unsigned long long* A = c->tmpA.as<unsigned long long>(); unsigned long long* B = A + nw * K;
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K), block(256);
         if (have_bits) { if (c->mask_bits == (const void*)B) std::swap(A, B); }        // the planes are already there (first or second half)
+        else if (labels_mode && (W & 63) == 0 && !getenv("ORIP_PACK_BYTES")) hipLaunchKernelGGL(k_bits_pack_labels, dim3(gw.x), block, 0, LN(c).stream, src, A, H, W, Ww, K);
         else hipLaunchKernelGGL(k_bits_pack, gw, block, 0, LN(c).stream, src, A, H, W, Ww, labels_mode ? 1 : 0);
         c->mask_bits = nullptr;
         for (size_t i = 0; i < passes.size(); i++) {
@@ -837,7 +861,8 @@ int orip_morph_open_close(orip_ctx* c, const u8* src, u8* dst, int K, int shape,
             hipLaunchKernelGGL(k_morph_bits, gw, block, 0, LN(c).stream, A, B, H, W, Ww, k, se, passes[i] == 1 ? 1 : 0);
             std::swap(A, B);
         }
-        if (unpack) hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
+        if (unpack && (W & 63) == 0 && !getenv("ORIP_PACK_BYTES")) hipLaunchKernelGGL(k_bits_expand16, dim3((unsigned)cdiv((int64_t)nw * 4, 256), 1, K), block, 0, LN(c).stream, A, dst, nw);
+        else if (unpack) hipLaunchKernelGGL(k_bits_unpack, dim3((unsigned)cdiv((int64_t)plane, 1024), 1, K), block, 0, LN(c).stream, A, dst, H, W, Ww);
         else c->morphed_bits = A;
         HIPC(c, hipGetLastError());
         if (labels_mode && dst == c->masks.as<u8>()) c->mask_bits = A;      // stage 03 can start from the bit planes

@@ -464,7 +464,8 @@ extern "C" int orip_detect_edges(orip_ctx* c, int morph_k, int open_iters, int c
         dim3 gw((unsigned)cdiv((int64_t)nw, 256), 1, K);
         { ProfScope ps(c, "k_hyst_mark"); hipLaunchKernelGGL(k_hyst_bits_mark, gw, block, 0, LN(c).stream, strong, c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), H, W, Ww); }
         { ProfScope ps(c, "k_hyst_out"); hipLaunchKernelGGL(k_hyst_bits_out, gw, block, 0, LN(c).stream, cand, c->tmpD.as<int>(), LN(c).tmpE.as<u8>(), ebits, H, W, Ww); }
-        hipLaunchKernelGGL(k_bits_to_bytes03, gw, block, 0, LN(c).stream, ebits, c->edges.as<u8>(), H, W, Ww);
+        if ((W & 63) == 0 && !getenv("ORIP_PACK_BYTES")) hipLaunchKernelGGL(k_bits_expand16, dim3((unsigned)cdiv((int64_t)H * Ww * 4, 256), 1, K), block, 0, LN(c).stream, ebits, c->edges.as<u8>(), (size_t)H * Ww);
+        else hipLaunchKernelGGL(k_bits_to_bytes03, gw, block, 0, LN(c).stream, ebits, c->edges.as<u8>(), H, W, Ww);
         HIPC(c, hipGetLastError());
         c->edge_bits = ebits;
         return 0;
