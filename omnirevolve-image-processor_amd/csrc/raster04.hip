@@ -109,6 +109,45 @@ __global__ __launch_bounds__(256) void k_compact_write(const u8* __restrict__ st
     }
 }
 
+// The same compaction from the thinned BIT planes ([K][H][Ww] words; a set bit = a skeleton pixel = ST_FG in the state plane): a thread owns a word, a
+// block 256 consecutive words of the flattened planes, i.e. the same (layer, row, column) order.  The byte form read 134 MB of state bytes at 4096^2 x 8,
+// four per thread (0.43 ms in front of the walks); the planes are 16 MB and almost empty.
+__global__ __launch_bounds__(256) void k_compact_count_bits(const unsigned long long* __restrict__ bits, size_t nwords, unsigned* __restrict__ counts) {
+    __shared__ unsigned wsum[4];
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned cnt = wi < nwords ? (unsigned)__popcll(bits[wi]) : 0u;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_compact_write_bits(const unsigned long long* __restrict__ bits, const int* __restrict__ par, size_t nwords, size_t nw, int H, int W, int Ww,
+                                                            const unsigned* __restrict__ block_off, unsigned* __restrict__ keys, unsigned* __restrict__ lin) {
+    __shared__ unsigned wsum[4];
+    const int Wb = (W + 1) >> 1, Hb = (H + 1) >> 1; const int64_t pplane = (int64_t)Wb * Hb * 4;
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long m = wi < nwords ? bits[wi] : 0ULL;
+    const unsigned cnt = (unsigned)__popcll(m);
+    unsigned inc = cnt;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (!m) return;
+    unsigned pos = block_off[blockIdx.x] + inc - cnt;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pos += wsum[w];
+    const int layer = (int)(wi / nw); const size_t wl = wi - (size_t)layer * nw;
+    const int y = (int)(wl / Ww), x0 = (int)(wl % Ww) * 64;
+    while (m) {
+        const int j = __ffsll((long long)m) - 1; m &= m - 1;
+        const int x = x0 + j;
+        const int id = (((y >> 1) * Wb + (x >> 1)) << 2) | ((y & 1) << 1) | (x & 1);
+        keys[pos] = ((unsigned)layer << 26) | (unsigned)par[pplane * layer + id];
+        lin[pos] = (unsigned)((int64_t)y * W + x);
+        pos++;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_heads(const unsigned* __restrict__ keys, int64_t m, unsigned* __restrict__ head) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
@@ -552,11 +591,16 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     if (!ORIP_VARIANT("ORIP_THIN_BYTES") && !getenv("ORIP_CCL_BYTES")) ORIP_TRY(orip_ccl_bits(c, LN(c).vtmp[10].as<unsigned long long>(), c->tmpD.as<int>(), K));
     else ORIP_TRY(orip_ccl(c, c->skel.as<u8>(), c->tmpD.as<int>(), K, 0));
     // ---- ordered compaction
-    const int nblk = cdiv(n, 1024);
+    const bool from_bits = !ORIP_VARIANT("ORIP_THIN_BYTES") && !getenv("ORIP_COMPACT_BYTES");       // the thinned bit planes are in vtmp[10]
+    const int Wwc = (W + 63) >> 6; const size_t nwc = (size_t)H * Wwc, nwords = nwc * K;
+    const unsigned long long* sk_bits = LN(c).vtmp[10].as<unsigned long long>();
+    const int nblk = from_bits ? (int)cdiv((int64_t)nwords, 256) : cdiv(n, 1024);
     HIPC(c, LN(c).tmpE.ensure((size_t)(nblk + 1) * 2 * sizeof(unsigned) + 64));
     unsigned* d_cnt = LN(c).tmpE.as<unsigned>(); unsigned* d_boff = d_cnt + nblk + 1;
     HIPC(c, hipMemsetAsync(d_cnt + nblk, 0, sizeof(unsigned), LN(c).stream));
-    { ProfScope ps(c, "k_compact_count"); hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), n, d_cnt); }
+    { ProfScope ps(c, "k_compact_count");
+      if (from_bits) hipLaunchKernelGGL(k_compact_count_bits, dim3(nblk), block, 0, LN(c).stream, sk_bits, nwords, d_cnt);
+      else hipLaunchKernelGGL(k_compact_count, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), n, d_cnt); }
     ORIP_TRY(excl_scan<unsigned>(c, d_cnt, d_boff, (size_t)nblk + 1, LN(c).tmpF));
     unsigned M = 0;
     HIPC(c, hipMemcpyAsync(&M, d_boff + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, LN(c).stream));
@@ -571,7 +615,9 @@ extern "C" int orip_contours_prepare(orip_ctx* c) {
     // keys / lin (double buffers for the sort)
     HIPC(c, LN(c).vtmp[0].ensure((size_t)M * 4 * 4 + 64));
     unsigned* keys_in = LN(c).vtmp[0].as<unsigned>(); unsigned* lin_in = keys_in + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
-    { ProfScope ps(c, "k_compact_write"); hipLaunchKernelGGL(k_compact_write, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), n, H, W, d_boff, keys_in, lin_in); }
+    { ProfScope ps(c, "k_compact_write");
+      if (from_bits) hipLaunchKernelGGL(k_compact_write_bits, dim3(nblk), block, 0, LN(c).stream, sk_bits, c->tmpD.as<int>(), nwords, nwc, H, W, Wwc, d_boff, keys_in, lin_in);
+      else hipLaunchKernelGGL(k_compact_write, dim3(nblk), block, 0, LN(c).stream, c->tmpC.as<u8>(), c->tmpD.as<int>(), n, H, W, d_boff, keys_in, lin_in); }
     {
         size_t bytes = 0;
         HIPC(c, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys, lin_in, lin, (size_t)M, 0, 30, LN(c).stream));
