@@ -336,6 +336,25 @@ __global__ __launch_bounds__(256) void k_bits_to_skel_state(const unsigned long 
         }
         if (d2bits) d2bits[nw * blockIdx.z + wi_of(w0, lane)] = d2;
     }
+    if ((W & 63) == 0) {          // a word is 64 whole pixels of one row: every lane writes the 64 skeleton and 64 state bytes of its own word, 16 bytes per store
+        if (w0 + lane >= nw) return;
+        const size_t px = (w0 + lane) * 64;                 // == y * W + 64 xw
+        uint4* ok = reinterpret_cast<uint4*>(sk + px); uint4* oo = reinterpret_cast<uint4*>(so + px);
+        auto spread = [](unsigned long long v, int g) { return ((((unsigned)(v >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u); };      // 4 bits -> 0 / 1 in 4 bytes
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int g = 4 * q + r;
+                const unsigned F = spread(fg, g);
+                a[r] = F * 0xffu;
+                b[r] = (F << 7) | spread(en, g) | (spread(ju, g) << 1) | (spread(d2, g) << 2);      // ST_FG 0x80, ST_END 1, ST_JUN 2, ST_DEG2 4 (en, ju, d2 are subsets of fg)
+            }
+            ok[q] = make_uint4(a[0], a[1], a[2], a[3]); oo[q] = make_uint4(b[0], b[1], b[2], b[3]);
+        }
+        return;
+    }
     auto bc = [&](unsigned long long v, int j) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
     };
