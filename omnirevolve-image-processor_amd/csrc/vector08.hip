@@ -1228,6 +1228,33 @@ __global__ __launch_bounds__(256) void k_sk_write(const u8* __restrict__ s, cons
     unsigned pos = base + inc - c;
     for (int j = 0; j < 4; j++) if (f[j]) { keys[pos] = (unsigned)L[i + j]; lin[pos] = (unsigned)(i + j); pos++; }
 }
+// the same ordered list from the thinned BIT plane (a word per thread, [Hp][Wwp] words; pixel index on the padded raster = y * Wp + x): 1 bit instead of
+// 1 byte per canvas pixel read, and almost every word is empty
+__global__ __launch_bounds__(256) void k_sk_count_bits(const unsigned long long* __restrict__ b, size_t nwords, unsigned* __restrict__ counts) {
+    __shared__ unsigned ws[4];
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned c = wi < nwords ? (unsigned)__popcll(b[wi]) : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void k_sk_write_bits(const unsigned long long* __restrict__ b, const int* __restrict__ L, size_t nwords, int Wp, int Wwp, const unsigned* __restrict__ boff,
+                                                       unsigned* __restrict__ keys, unsigned* __restrict__ lin) {
+    __shared__ unsigned ws[4];
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long m = wi < nwords ? b[wi] : 0ULL;
+    const unsigned c = (unsigned)__popcll(m);
+    unsigned inc = c; const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (!m) return;
+    unsigned pos = boff[blockIdx.x] + inc - c;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pos += ws[w];
+    const size_t p0 = (wi / Wwp) * (size_t)Wp + (wi % Wwp) * 64;
+    while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; const size_t p = p0 + j; keys[pos] = (unsigned)L[p]; lin[pos] = (unsigned)p; pos++; }
+}
 __global__ __launch_bounds__(256) void k_heads2(const unsigned* __restrict__ keys, int64_t m, unsigned* __restrict__ head) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i > m) return;
     head[i] = (i < m && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
@@ -1981,17 +2008,20 @@ extern "C" int orip_dedup_layer(orip_ctx* c, int layer, const orip_params08* prm
         }
 #endif
         tick("c:ccl");
-        const int nblk = cdiv((int64_t)Np, 1024);
+        const bool sk_bits = !ORIP_VARIANT("ORIP_THIN_BYTES") && !getenv("ORIP_SK_BYTES");          // the thinned bit plane is in bA
+        const int nblk = sk_bits ? (int)cdiv((int64_t)nwords, 256) : cdiv((int64_t)Np, 1024);
         HIPC(c, LN(c).vtmp[0].ensure((size_t)(nblk + 1) * 8 + 64));
         unsigned* bc = LN(c).vtmp[0].as<unsigned>(); unsigned* bo = bc + (nblk + 1);
         HIPC(c, hipMemsetAsync(bc + nblk, 0, 4, LN(c).stream));
-        hipLaunchKernelGGL(k_sk_count, dim3(nblk), blk, 0, LN(c).stream, skA, (int64_t)Np, bc);
+        if (sk_bits) hipLaunchKernelGGL(k_sk_count_bits, dim3(nblk), blk, 0, LN(c).stream, bA, nwords, bc);
+        else hipLaunchKernelGGL(k_sk_count, dim3(nblk), blk, 0, LN(c).stream, skA, (int64_t)Np, bc);
         ORIP_TRY(vscan_excl<unsigned>(c, bc, bo, (size_t)nblk + 1));
         unsigned M = 0; ORIP_TRY(vread(c, &M, bo + nblk));
         if (M > 0) {
             HIPC(c, LN(c).vtmp[1].ensure((size_t)M * 16 + 64));
             unsigned* kin = LN(c).vtmp[1].as<unsigned>(); unsigned* lin_in = kin + M; unsigned* keys = lin_in + M; unsigned* lin = keys + M;
-            hipLaunchKernelGGL(k_sk_write, dim3(nblk), blk, 0, LN(c).stream, skA, L2, (int64_t)Np, bo, kin, lin_in);
+            if (sk_bits) hipLaunchKernelGGL(k_sk_write_bits, dim3(nblk), blk, 0, LN(c).stream, bA, L2, nwords, Wp, Wwp, bo, kin, lin_in);
+            else hipLaunchKernelGGL(k_sk_write, dim3(nblk), blk, 0, LN(c).stream, skA, L2, (int64_t)Np, bo, kin, lin_in);
             ORIP_TRY((vsort_pairs<unsigned, unsigned>(c, kin, keys, lin_in, lin, (size_t)M, 0, 27)));
             HIPC(c, LN(c).vtmp[3].ensure((size_t)(M + 1) * 8 + 64));
             unsigned* head = LN(c).vtmp[3].as<unsigned>(); unsigned* hs = head + (M + 1);
